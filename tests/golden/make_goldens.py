@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE'S OWN SOURCE
+(/root/reference/dpc/util/{point_cloud,drc,gauss_kernel,quaternion,camera}.py,
+imported unchanged) under the eager TensorFlow shim in oracle/tf_shim.
+
+Runs in the build container only (needs /root/reference); the .npz fixtures
+are data (inputs + expected outputs) and are what travels.  Each case is run in
+fp32 (the reference's arithmetic; keys ``*_f32``) and in fp64 (error
+budgeting / truth; keys ``*_f64``).  Gradients come from torch autograd
+through the reference code (cross-checked against the hand-derived backward of
+oracle/dpc_oracle_np.py by tests/test_oracle.py).
+
+    python tests/golden/make_goldens.py
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle", "tf_shim"))
+sys.path.insert(0, "/root/reference/dpc")
+sys.path.insert(0, ROOT)
+
+import tensorflow as tf  # noqa: E402  (the shim)
+from util import point_cloud as ref_pc  # noqa: E402  (reference, unchanged)
+from util import gauss_kernel as ref_gk  # noqa: E402
+from util import drc as ref_drc  # noqa: E402
+
+synth = importlib.import_module("differentiable-point-clouds_amd.synthetic")
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def make_cfg(**kw):
+    c = Cfg(vox_size=64, vox_size_z=-1, camera_distance=2.0, focal_length=1.875,
+            pose_quaternion=True, pc_gauss_kernel_size=11, pc_separable_gauss_filter=True,
+            ptn_max_projection=False, drc_logsum=True, drc_logsum_clip_val=1e-5,
+            drc_tf_cumulative=True, max_depth=10.0, pc_rgb_stop_points_gradient=False,
+            pc_rgb_clip_after_conv=False, pc_rgb_divide_by_occupancies=False,
+            pc_rgb_divide_by_occupancies_epsilon=0.01)
+    c.update(kw)
+    return c
+
+
+def run_reference(cfg, inp, sigma, dtype, upstream, want_grads=True, use_kernel=True):
+    """inp: dict of numpy arrays (pc, pose, [trans], [scale], [focal]).
+    upstream: dict of numpy weights for the scalar loss
+       L = sum(w_proj*proj) + sum(w_depth*proj_depth) + sum(w_probs*drc_probs)
+    (all in the reference's output layouts)."""
+    tf.set_float_dtype(dtype)
+    leaves = {}
+    for k in ("pc", "pose", "trans", "scale", "focal"):
+        if inp.get(k) is not None:
+            leaves[k] = torch.tensor(inp[k], dtype=dtype, requires_grad=want_grads)
+    kern = ref_gk.smoothing_kernel(cfg, sigma) if use_kernel else None
+    T = lambda k: tf.convert_to_tensor(leaves[k]) if k in leaves else None
+    out = ref_pc.pointcloud_project_fast(cfg, T("pc"), T("pose"), T("trans"), None, kern,
+                                         scaling_factor=T("scale"), focal_length=T("focal"))
+    res = {}
+    for k in ("proj", "voxels", "tr_pc", "drc_probs", "proj_depth"):
+        if out[k] is not None:
+            res[k] = out[k].detach().numpy().copy()
+    if kern is not None:
+        res["taps_x"] = kern[0].detach().numpy().reshape(-1)
+        res["taps_y"] = kern[1].detach().numpy().reshape(-1)
+        res["taps_z"] = kern[2].detach().numpy().reshape(-1)
+    if want_grads:
+        loss = 0.0
+        for name, key in (("w_proj", "proj"), ("w_depth", "proj_depth"), ("w_probs", "drc_probs")):
+            if upstream.get(name) is not None:
+                loss = loss + (torch.tensor(upstream[name], dtype=dtype) * out[key]).sum()
+        loss.backward()
+        for k, t in leaves.items():
+            res["d" + k] = t.grad.numpy().copy() if t.grad is not None else np.zeros_like(inp[k])
+    tf.set_float_dtype(torch.float32)
+    return res
+
+
+def stage_outputs(cfg, inp, sigma, dtype):
+    """Stage-level intermediates via the reference's finer-grained functions."""
+    tf.set_float_dtype(dtype)
+    T = lambda k: tf.convert_to_tensor(torch.tensor(inp[k], dtype=dtype)) if inp.get(k) is not None else None
+    tr = ref_pc.pc_perspective_transform(cfg, T("pc"), T("pose"), T("trans"), T("focal"))
+    raw, _ = ref_pc.pointcloud2voxels3d_fast(cfg, tr, None)
+    clipped = tf.clip_by_value(tf.expand_dims(raw, -1), 0.0, 1.0)
+    blur = ref_pc.smoothen_voxels3d(cfg, clipped, ref_gk.smoothing_kernel(cfg, sigma))
+    tf.set_float_dtype(torch.float32)
+    return dict(grid_raw=raw.numpy().copy(), grid_blur=blur.numpy()[..., 0].copy())
+
+
+def digest(g, rng_seed=7, n=256):
+    g = np.asarray(g, np.float64).reshape(-1)
+    idx = np.random.default_rng(rng_seed).integers(0, g.size, n)
+    return dict(sum=g.sum(), sumsq=(g * g).sum(), idx=idx, val=g[idx])
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: v for k, v in arrays.items() if v is not None})
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024.0))
+
+
+def both(cfg, inp, sigma, upstream, **kw):
+    r32 = run_reference(cfg, inp, sigma, torch.float32, upstream, **kw)
+    r64 = run_reference(cfg, inp, sigma, torch.float64, upstream, **kw)
+    out = {}
+    for k, v in r32.items():
+        out[k + "_f32"] = v.astype(np.float32)
+    for k, v in r64.items():
+        out[k + "_f64"] = v.astype(np.float64)
+    return out
+
+
+def tiny_inputs(seed=11, B=2, N=64, with_trans=True, with_scale=True, with_focal=False):
+    rng = np.random.default_rng(seed)
+    pc = rng.uniform(-0.42, 0.42, (B, N, 3)).astype(np.float32)
+    pc[:, :4, :] = rng.uniform(0.75, 0.95, (B, 4, 3)) * rng.choice([-1.0, 1.0], (B, 4, 3))  # out of cube
+    inp = dict(pc=pc.astype(np.float32), pose=rng.standard_normal((B, 4)).astype(np.float32))
+    if with_trans:
+        inp["trans"] = (0.05 * rng.standard_normal((B, 3))).astype(np.float32)
+    if with_scale:
+        inp["scale"] = rng.uniform(0.5, 1.0, (B, 1)).astype(np.float32)
+    if with_focal:
+        inp["focal"] = rng.uniform(1.7, 2.1, (B, 1)).astype(np.float32)
+    return inp
+
+
+def rand_upstream(seed, B, Dz, D, depth=True, probs=False):
+    rng = np.random.default_rng(seed)
+    up = dict(w_proj=rng.standard_normal((B, D, D, 1)).astype(np.float32))
+    if depth:
+        up["w_depth"] = (0.1 * rng.standard_normal((B, D, D, 1))).astype(np.float32)
+    if probs:
+        up["w_probs"] = (0.2 * rng.standard_normal((Dz + 1, B, D, D, 1))).astype(np.float32)
+    return up
+
+
+def main():
+    # ---- tiny: everything, with translation + scaling + outliers --------------------
+    cfg = make_cfg(vox_size=16, pc_gauss_kernel_size=5)
+    inp = tiny_inputs()
+    up = rand_upstream(3, 2, 16, 16, depth=True, probs=False)
+    g = both(cfg, inp, 0.8, up)
+    st32 = stage_outputs(cfg, inp, 0.8, torch.float32)
+    st64 = stage_outputs(cfg, inp, 0.8, torch.float64)
+    save("tiny", sigma=0.8, K=5, D=16, Dz=16, **inp, **up, **g,
+         grid_raw_f32=st32["grid_raw"], grid_blur_f32=st32["grid_blur"],
+         grid_raw_f64=st64["grid_raw"], grid_blur_f64=st64["grid_blur"])
+
+    # ---- tiny with gradient flowing in through drc_probs as well -------------------
+    up = rand_upstream(4, 2, 16, 16, depth=True, probs=True)
+    save("tiny_probs_grad", sigma=0.8, K=5, D=16, Dz=16, **inp, **up, **both(cfg, inp, 0.8, up))
+
+    # ---- tiny, per-instance focal length, no translation ---------------------------
+    inp_f = tiny_inputs(seed=12, with_trans=False, with_focal=True)
+    up = rand_upstream(5, 2, 16, 16)
+    save("tiny_focal", sigma=0.8, K=5, D=16, Dz=16, **inp_f, **up, **both(cfg, inp_f, 0.8, up))
+
+    # ---- tiny forward-only with NaN / inf points -----------------------------------
+    inp_n = tiny_inputs(seed=13)
+    inp_n["pc"][0, 10, 1] = np.nan
+    inp_n["pc"][1, 20, 0] = np.inf
+    g = both(cfg, inp_n, 0.8, {}, want_grads=False)
+    save("tiny_nan", sigma=0.8, K=5, D=16, Dz=16, **inp_n, **g)
+
+    # ---- variants -----------------------------------------------------------------
+    inp_v = tiny_inputs(seed=14)
+    up = rand_upstream(6, 2, 16, 16)
+    save("tiny_nokernel", D=16, Dz=16, **inp_v, **up, **both(cfg, inp_v, 0.8, up, use_kernel=False))
+    inp_ns = dict(inp_v)
+    inp_ns.pop("scale")
+    save("tiny_noscale", sigma=0.8, K=5, D=16, Dz=16, **inp_ns, **up, **both(cfg, inp_ns, 0.8, up))
+
+    cfg_max = make_cfg(vox_size=16, pc_gauss_kernel_size=5, ptn_max_projection=True)
+    up_m = dict(w_proj=up["w_proj"])
+    save("tiny_maxproj", sigma=0.8, K=5, D=16, Dz=16, **inp_v, **up_m, **both(cfg_max, inp_v, 0.8, up_m))
+
+    cfg_z = make_cfg(vox_size=16, vox_size_z=8, pc_gauss_kernel_size=5)
+    up_z = rand_upstream(8, 2, 8, 16)
+    save("tiny_voxz", sigma=0.8, K=5, D=16, Dz=8, **inp_v, **up_z, **both(cfg_z, inp_v, 0.8, up_z))
+
+    # matrix pose: E = [R(q_hat) | (cd,0,0)] in the internal (depth,y,x) convention
+    cfg_m = make_cfg(vox_size=16, pc_gauss_kernel_size=5, pose_quaternion=False)
+    q = inp_v["pose"].astype(np.float64)
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+                  np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+                  np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], 1)
+    E = np.zeros((2, 4, 4))
+    E[:, :3, :3] = R
+    E[:, 0, 3] = 2.0
+    E[:, 3, 3] = 1.0
+    inp_m = dict(pc=inp_v["pc"], pose=E.astype(np.float32), scale=inp_v["scale"])
+    save("tiny_matrix", sigma=0.8, K=5, D=16, Dz=16, **inp_m, **up, **both(cfg_m, inp_m, 0.8, up))
+
+    # ---- K=21, sigma=3 at D=32 (the shipped experiments' kernel size) ---------------
+    cfg21 = make_cfg(vox_size=32, pc_gauss_kernel_size=21)
+    inp21 = synth.make_inputs(2, 500, 99)
+    gt = synth.disk_gt(2, 32)
+    r = run_reference(cfg21, inp21, 3.0, torch.float32, {}, want_grads=False)
+    up21 = dict(w_proj=((r["proj"] - gt) / 2).astype(np.float32))
+    g21 = {k: v for k, v in both(cfg21, inp21, 3.0, up21).items() if not k.startswith(("voxels", "drc_probs"))}
+    save("k21", sigma=3.0, K=21, D=32, Dz=32, **inp21, **up21, **g21)
+
+    # ---- cfg1: B=4, N=1000, 64^3, K=11, sigma=1.0, dproj = (proj - gt)/B -----------
+    c1 = synth.config_inputs(1)
+    cfg1 = make_cfg(vox_size=64, pc_gauss_kernel_size=11)
+    inp1 = dict(pc=c1["pc"], pose=c1["pose"], scale=c1["scale"])
+    gt = synth.disk_gt(4, 64)
+    r = run_reference(cfg1, inp1, 1.0, torch.float32, {}, want_grads=False)
+    up1 = dict(w_proj=((r["proj"] - gt) / 4).astype(np.float32))
+    g = both(cfg1, inp1, 1.0, up1)
+    st = stage_outputs(cfg1, inp1, 1.0, torch.float64)
+    d0, d1 = digest(st["grid_raw"]), digest(st["grid_blur"])
+    for k in list(g):
+        if k.startswith(("voxels", "drc_probs")):
+            g.pop(k)                                   # too large; digests instead
+    save("cfg1", sigma=1.0, K=11, D=64, Dz=64, **inp1, **up1, **g,
+         raw_sum=d0["sum"], raw_sumsq=d0["sumsq"], raw_idx=d0["idx"], raw_val=d0["val"],
+         blur_sum=d1["sum"], blur_sumsq=d1["sumsq"], blur_idx=d1["idx"], blur_val=d1["val"])
+
+    # ---- mid: B=1, N=8000, 128^3, K=11, sigma=1.6 ----------------------------------
+    c2 = synth.config_inputs(2, B=1)
+    cfg2 = make_cfg(vox_size=128, pc_gauss_kernel_size=11)
+    inp2 = dict(pc=c2["pc"], pose=c2["pose"], scale=c2["scale"])
+    gt = synth.disk_gt(1, 128)
+    r = run_reference(cfg2, inp2, 1.6, torch.float32, {}, want_grads=False)
+    up2 = dict(w_proj=((r["proj"] - gt) / 1).astype(np.float32))
+    g = both(cfg2, inp2, 1.6, up2)
+    st = stage_outputs(cfg2, inp2, 1.6, torch.float64)
+    d0, d1 = digest(st["grid_raw"]), digest(st["grid_blur"])
+    keep = {k: v for k, v in g.items() if k.startswith(("proj_", "proj_depth", "dpc", "dpose", "dscale", "tr_pc"))}
+    save("mid", sigma=1.6, K=11, D=128, Dz=128, **inp2, **up2, **keep,
+         raw_sum=d0["sum"], raw_sumsq=d0["sumsq"], raw_idx=d0["idx"], raw_val=d0["val"],
+         blur_sum=d1["sum"], blur_sumsq=d1["sumsq"], blur_idx=d1["idx"], blur_val=d1["val"])
+
+
+if __name__ == "__main__":
+    main()
