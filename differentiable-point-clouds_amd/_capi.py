@@ -1,0 +1,118 @@
+"""ctypes binding of the C ABI in include/dpc_hip.h.
+
+The product path loads exactly one library, ``csrc/libdpc_hip.so`` (hipcc,
+gfx950), and fails loudly if it is missing or if a tensor is not on a ROCm
+device: there is NO CPU fallback.  (The test-suite can install the CPU
+*emulation build of the same kernel source* with ``set_library`` -- see
+tests/hipemu -- to check kernel logic without a GPU; nothing in this package
+does that on its own.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdpc_hip.so")
+
+DPC_COLLAPSE_DRC = 0
+DPC_COLLAPSE_MAX = 1
+DPC_MAX_TAPS = 63
+
+_ERRORS = {
+    -1: "DPC_E_NULL (required pointer is null)",
+    -2: "DPC_E_SHAPE (non-positive or unsupported sizes)",
+    -3: "DPC_E_TAPS (even or too large kernel size)",
+    -4: "DPC_E_WORKSPACE (workspace too small or misaligned)",
+    -5: "DPC_E_MODE (unsupported parameter combination)",
+}
+
+
+class DpcShape(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("Dz", ctypes.c_int32),
+                ("D", ctypes.c_int32), ("Kx", ctypes.c_int32), ("Ky", ctypes.c_int32),
+                ("Kz", ctypes.c_int32)]
+
+
+class DpcParams(ctypes.Structure):
+    _fields_ = [("camera_distance", ctypes.c_float), ("focal_length", ctypes.c_float),
+                ("eps", ctypes.c_float), ("max_depth", ctypes.c_float),
+                ("pose_is_quaternion", ctypes.c_int32), ("collapse_mode", ctypes.c_int32),
+                ("flags", ctypes.c_int32)]
+
+
+_P = ctypes.c_void_p
+_SP = ctypes.POINTER(DpcShape)
+_PP = ctypes.POINTER(DpcParams)
+
+# name -> (restype, argtypes); mirrors include/dpc_hip.h one to one
+SIGNATURES = {
+    "dpc_version": (ctypes.c_char_p, []),
+    "dpc_workspace_bytes": (ctypes.c_size_t, [_SP, ctypes.c_int]),
+    "dpc_project_forward": (ctypes.c_int, [_P, _SP, _PP] + [_P] * 8 + [_P] * 6 + [_P, ctypes.c_size_t]),
+    "dpc_project_backward": (ctypes.c_int, [_P, _SP, _PP] + [_P] * 8 + [_P] * 4 + [_P] * 3 + [_P] * 5
+                             + [_P, ctypes.c_size_t]),
+    "dpc_transform_fwd": (ctypes.c_int, [_P, _SP, _PP] + [_P] * 5),
+    "dpc_transform_bwd": (ctypes.c_int, [_P, _SP, _PP] + [_P] * 10),
+    "dpc_voxelize_fwd": (ctypes.c_int, [_P, _SP, _P, _P]),
+    "dpc_voxelize_bwd": (ctypes.c_int, [_P, _SP, _P, _P, _P]),
+    "dpc_blur3d": (ctypes.c_int, [_P, _SP] + [_P] * 6 + [ctypes.c_int]),
+    "dpc_drc_fwd": (ctypes.c_int, [_P, _SP, _PP, _P, _P, _P, ctypes.c_int]),
+    "dpc_drc_bwd": (ctypes.c_int, [_P, _SP, _PP, _P, _P, _P, _P, ctypes.c_int]),
+    "dpc_max_collapse_fwd": (ctypes.c_int, [_P, _SP, _P, _P, ctypes.c_int]),
+    "dpc_max_collapse_bwd": (ctypes.c_int, [_P, _SP, _P, _P, _P, ctypes.c_int]),
+}
+
+
+class DpcError(RuntimeError):
+    pass
+
+
+class DpcLibrary(object):
+    """A loaded C-ABI library.  ``host_memory`` marks the CPU emulation build
+    (pointers are host pointers, no stream); only tests create such objects."""
+
+    def __init__(self, path, host_memory=False):
+        if not os.path.exists(path):
+            raise DpcError("%s not found" % path)
+        self.path = path
+        self.host_memory = bool(host_memory)
+        self._dll = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self._dll, name)        # AttributeError if a symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+
+    def version(self):
+        return self.dpc_version().decode()
+
+    @staticmethod
+    def check(rc, what):
+        if rc == 0:
+            return
+        if rc < 0:
+            raise DpcError("%s: %s" % (what, _ERRORS.get(rc, "error %d" % rc)))
+        raise DpcError("%s: hipError_t %d" % (what, rc))
+
+
+_ACTIVE = None
+
+
+def get_library():
+    """The product loader: libdpc_hip.so or an exception.  Never falls back."""
+    global _ACTIVE
+    if _ACTIVE is None:
+        if not os.path.exists(LIB_PATH):
+            raise DpcError(
+                "HIP extension %s is not built. Build it with `python __graft_entry__.py` "
+                "(or `make -C differentiable-point-clouds_amd/csrc`). There is no CPU fallback."
+                % LIB_PATH)
+        _ACTIVE = DpcLibrary(LIB_PATH, host_memory=False)
+    return _ACTIVE
+
+
+def set_library(lib):
+    """Install a specific DpcLibrary (tests only: CPU emulation of the kernels).
+    Returns the previously active one (possibly None)."""
+    global _ACTIVE
+    prev, _ACTIVE = _ACTIVE, lib
+    return prev

@@ -1,0 +1,1368 @@
+// dpc_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) and the
+// C ABI (include/dpc_hip.h) of the differentiable point-cloud projector.
+//
+// What runs where (per instance b; grids are [B,Dz,D,D], x fastest):
+//
+//   forward   k_points_fwd     thread/point: camera transform (quaternion or
+//                              matrix) + 8 trilinear global_atomic_add_f32
+//                              into the zero-filled raw grid G0
+//             k_blur_plane     WG = (b, z, y-tile): clip + x-blur + y-blur of a
+//                              plane tile staged in LDS (odd pitches => both
+//                              passes are bank-conflict free; sliding register
+//                              windows => ~2 LDS reads / output instead of K)
+//             k_zfwd           thread = CX adjacent rays: streams the z axis
+//                              once, z-FIR in registers, writes G2 (saved) and
+//                              collapses the ray on the fly (scale, clips,
+//                              log-space DRC, depth) -> proj, depth, log T
+//   backward  k_zbwd           thread = CX rays, streams z DOWNWARD: DRC VJP
+//                              (direct suffix sums, S_j = logT - R_j in fp64),
+//                              scale/clip masks, z-FIR adjoint -> dGz, dscale
+//             k_blur_plane     y-blur only (adjoint)
+//             k_points_bwd     thread/point: x-blur evaluated ONLY at the 8
+//                              touched cells (sparse), G0 clip mask, trilinear
+//                              gather, camera-transform VJP, block reduction of
+//                              dq/dt/df, atomics into a [B,16] accumulator
+//             k_pose_finalize  quaternion normalisation Jacobian
+//
+// HBM traffic per view: forward 5 V (zero G0, r/w xy-blur, r in / w G2),
+// backward 4 V (+ sparse) against the 8 V "algorithmic" model of SURVEY.md 8(d).
+// No MFMA: this is scatter / stencil / scan work bounded by HBM.
+//
+// The same source compiles for the CPU-only test tier with -DDPC_EMU (see
+// tests/hipemu/hip_emu.h); that build is never loaded by the product.
+
+#include "dpc_hip.h"
+
+#ifdef DPC_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#define DPC_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__)
+#define DPC_DYN_SMEM(type, name)                                             \
+  extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; \
+  type* name = reinterpret_cast<type*>(name##_raw)
+#endif
+
+#include <math.h>
+
+#define DPC_BLOCK 256
+#define DPC_XC 8  // x-blur outputs per thread (register window)
+#define DPC_YC 8  // y-blur outputs per thread
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fmaxf(fminf(v, hi), lo); }
+
+struct Quat {
+  float w, x, y, z;
+};
+__device__ __forceinline__ Quat qmul(const Quat& a, const Quat& b) {  // quaternion.py:62-78
+  Quat r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  return r;
+}
+__device__ __forceinline__ Quat qconj(const Quat& a) {
+  Quat r = {a.w, -a.x, -a.y, -a.z};
+  return r;
+}
+
+// Sum NV per-thread values over the block.  Result valid in thread 0 only.
+// Must be called by every thread of the block (block-uniform control flow).
+template <int NV>
+__device__ __forceinline__ void block_reduce_sum(float (&v)[NV]) {
+  __shared__ float red[NV * (DPC_BLOCK / 64)];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float s = v[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) red[wave * NV + i] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float s = 0.f;
+      for (int w = 0; w < nw; ++w) s += red[w * NV + i];
+      v[i] = s;
+    }
+  }
+  __syncthreads();
+}
+
+// exact floor(item / d) for 0 <= item < 2^20, 1 <= d <= 2^10
+__device__ __forceinline__ int fast_div(int item, int d, float inv_d) {
+  (void)d;
+  return (int)(((float)item + 0.5f) * inv_d);
+}
+
+// ---------------------------------------------------------------------------
+// camera pose, loaded per thread (uniform per block => scalar loads)
+// ---------------------------------------------------------------------------
+struct Pose {
+  Quat q;       // normalised quaternion            (quaternion branch)
+  float qnorm;  // |q| before normalisation
+  float M[12];  // rows 0..2 of diag(1,f,f,1) * E   (matrix branch)
+  float t[3];
+  float f;
+  float cd;
+  bool has_t;
+};
+
+template <bool QUAT>
+__device__ __forceinline__ void load_pose(const DpcParams& P, const float* __restrict__ pose,
+                                          const float* __restrict__ trans,
+                                          const float* __restrict__ focal, int b, Pose& o) {
+  o.cd = P.camera_distance;
+  o.has_t = false;
+  o.t[0] = o.t[1] = o.t[2] = 0.f;
+  if (QUAT) {
+    const float* q = pose + 4 * b;
+    const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);  // tf.norm
+    o.qnorm = n;
+    o.q.w = q[0] / n;
+    o.q.x = q[1] / n;
+    o.q.y = q[2] / n;
+    o.q.z = q[3] / n;
+    o.f = focal ? focal[b] : P.focal_length;
+    if (trans) {
+      o.has_t = true;
+      o.t[0] = trans[3 * b + 0];
+      o.t[1] = trans[3 * b + 1];
+      o.t[2] = trans[3 * b + 2];
+    }
+  } else {
+    const float* E = pose + 16 * b;
+    o.f = P.focal_length;  // camera.py:5-13: the matrix branch always uses cfg.focal_length
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o.M[0 * 4 + j] = E[0 * 4 + j];
+      o.M[1 * 4 + j] = o.f * E[1 * 4 + j];
+      o.M[2 * 4 + j] = o.f * E[2 * 4 + j];
+    }
+  }
+}
+
+// pc_perspective_transform (point_cloud.py:157-216): p -> (w=depth, v=y, u=x)
+template <bool QUAT>
+__device__ __forceinline__ void transform_point(const Pose& ps, float p0, float p1, float p2,
+                                                float& w, float& v, float& u) {
+  if (QUAT) {
+    Quat P = {0.f, p0, p1, p2};
+    Quat r = qmul(qmul(ps.q, P), qconj(ps.q));
+    float d = r.x, y = r.y, x = r.z;
+    if (ps.has_t) {
+      d += ps.t[0];
+      y += ps.t[1];
+      x += ps.t[2];
+    }
+    float zs = d + ps.cd;
+    float xs = x * ps.f;
+    float ys = y * ps.f;
+    xs = xs / zs;
+    ys = ys / zs;
+    zs = zs - ps.cd;
+    if (ps.has_t) zs = zs - ps.t[0];
+    w = zs;
+    v = ys;
+    u = xs;
+  } else {
+    const float* M = ps.M;
+    float zs = M[0] * p0 + M[1] * p1 + M[2] * p2 + M[3];
+    float ys = M[4] * p0 + M[5] * p1 + M[6] * p2 + M[7];
+    float xs = M[8] * p0 + M[9] * p1 + M[10] * p2 + M[11];
+    u = xs / zs;
+    v = ys / zs;
+    w = zs - ps.cd;
+  }
+}
+
+// VJP of transform_point.  acc[16]: quaternion: [0..3]=dq_hat, [4..6]=dtrans,
+// [7]=dfocal; matrix: [0..11]=dM (rows 0..2 of d(intr*E)).
+template <bool QUAT>
+__device__ __forceinline__ void transform_point_bwd(const Pose& ps, float p0, float p1, float p2,
+                                                    float dw, float dv, float du, float& g0,
+                                                    float& g1, float& g2, float (&acc)[16]) {
+  if (QUAT) {
+    Quat P = {0.f, p0, p1, p2};
+    Quat t = qmul(ps.q, P);
+    Quat r = qmul(t, qconj(ps.q));
+    float d = r.x, y = r.y, x = r.z;
+    if (ps.has_t) {
+      d += ps.t[0];
+      y += ps.t[1];
+      x += ps.t[2];
+    }
+    const float Z = d + ps.cd;
+    const float u = ps.f * x / Z, v = ps.f * y / Z;
+    const float dx = du * ps.f / Z;
+    const float dy = dv * ps.f / Z;
+    const float dZ = -(du * u + dv * v) / Z;
+    acc[7] += (du * x + dv * y) / Z;
+    acc[4] += dZ;  // d w / d t0 cancels (w = Z - cd - t0)
+    acc[5] += dy;
+    acc[6] += dx;
+    Quat dr = {0.f, dw + dZ, dy, dx};
+    // reverse of r = t (x) q*, t = q (x) P:  <dc, a(x)b>  =>  da = dc (x) b*, db = a* (x) dc
+    Quat dt = qmul(dr, ps.q);
+    Quat dqc = qmul(qconj(t), dr);
+    Quat dq2 = qmul(dt, qconj(P));
+    acc[0] += dqc.w + dq2.w;
+    acc[1] += -dqc.x + dq2.x;
+    acc[2] += -dqc.y + dq2.y;
+    acc[3] += -dqc.z + dq2.z;
+    Quat dP = qmul(qconj(ps.q), dt);
+    g0 = dP.x;
+    g1 = dP.y;
+    g2 = dP.z;
+  } else {
+    const float* M = ps.M;
+    const float Z = M[0] * p0 + M[1] * p1 + M[2] * p2 + M[3];
+    const float ys = M[4] * p0 + M[5] * p1 + M[6] * p2 + M[7];
+    const float xs = M[8] * p0 + M[9] * p1 + M[10] * p2 + M[11];
+    const float u = xs / Z, v = ys / Z;
+    const float d2 = du / Z, d1 = dv / Z, d0 = dw - (du * u + dv * v) / Z;
+    const float h[4] = {p0, p1, p2, 1.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[0 + j] += d0 * h[j];
+      acc[4 + j] += d1 * h[j];
+      acc[8 + j] += d2 * h[j];
+    }
+    g0 = d0 * M[0] + d1 * M[4] + d2 * M[8];
+    g1 = d0 * M[1] + d1 * M[5] + d2 * M[9];
+    g2 = d0 * M[2] + d1 * M[6] + d2 * M[10];
+  }
+}
+
+// pointcloud2voxels3d_fast cell lookup (point_cloud.py:76-92)
+struct Cell {
+  int iz, iy, ix;
+  float rz, ry, rx;
+  bool valid;
+};
+__device__ __forceinline__ Cell locate(float w, float v, float u, int Dz, int D) {
+  Cell c;
+  c.valid = (w >= -0.5f) && (w <= 0.5f) && (v >= -0.5f) && (v <= 0.5f) && (u >= -0.5f) && (u <= 0.5f);
+  const float gz = (w + 0.5f) * (float)(Dz - 1);
+  const float gy = (v + 0.5f) * (float)(D - 1);
+  const float gx = (u + 0.5f) * (float)(D - 1);
+  const float fz = floorf(gz), fy = floorf(gy), fx = floorf(gx);
+  c.iz = c.valid ? (int)fz : 0;
+  c.iy = c.valid ? (int)fy : 0;
+  c.ix = c.valid ? (int)fx : 0;
+  c.rz = gz - fz;
+  c.ry = gy - fy;
+  c.rx = gx - fx;
+  return c;
+}
+
+__device__ __forceinline__ void scatter_point(float* __restrict__ grid, int b, int Dz, int D, float w,
+                                              float v, float u) {
+  const Cell c = locate(w, v, u, Dz, D);
+  if (!c.valid) return;
+  const float wz[2] = {1.0f - c.rz, c.rz};
+  const float wy[2] = {1.0f - c.ry, c.ry};
+  const float wx[2] = {1.0f - c.rx, c.rx};
+  float* g = grid + (size_t)b * Dz * D * D;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const int zz = c.iz + k, yy = c.iy + j, xx = c.ix + l;
+        if (zz < Dz && yy < D && xx < D)  // == size only with weight 0 (coordinate exactly +0.5)
+          atomicAdd(g + ((size_t)zz * D + yy) * D + xx, wz[k] * wy[j] * wx[l]);
+      }
+}
+
+// Trilinear gather VJP.  dgrid is either d(G0) itself (Kx == 0, mask == null)
+// or the (z,y)-blurred gradient, in which case the x-blur (taps_x, Kx) is
+// evaluated here, only at the <= 8 touched cells, and `mask` (= G0) applies
+// the clip_by_value(.,0,1) gradient mask of point_cloud.py:240.
+__device__ __forceinline__ void gather_point(const float* __restrict__ dgrid,
+                                             const float* __restrict__ mask,
+                                             const float* __restrict__ taps_x, int Kx, int b, int Dz,
+                                             int D, float w, float v, float u, float& dw, float& dv,
+                                             float& du) {
+  dw = dv = du = 0.f;
+  const Cell c = locate(w, v, u, Dz, D);
+  if (!c.valid) return;  // boolean_mask gradient: zeros at dropped rows
+  const float wz[2] = {1.0f - c.rz, c.rz};
+  const float wy[2] = {1.0f - c.ry, c.ry};
+  const float wx[2] = {1.0f - c.rx, c.rx};
+  const size_t base_b = (size_t)b * Dz * D * D;
+  const int h = Kx >> 1;
+  float drz = 0.f, dry = 0.f, drx = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int zz = c.iz + k, yy = c.iy + j;
+      if (zz >= Dz || yy >= D) continue;
+      const size_t row = base_b + ((size_t)zz * D + yy) * D;
+      float g[2] = {0.f, 0.f};
+      if (Kx > 0) {
+        // window x in [ix-h, ix+1+h]; tap m of output l sits at x = ix + l + m - h
+        for (int m = 0; m <= Kx; ++m) {
+          const int x = c.ix - h + m;
+          if (x < 0 || x >= D) continue;
+          const float val = dgrid[row + x];
+          if (m < Kx) g[0] += taps_x[m] * val;
+          if (m >= 1) g[1] += taps_x[m - 1] * val;
+        }
+      } else {
+        g[0] = dgrid[row + c.ix];
+        if (c.ix + 1 < D) g[1] = dgrid[row + c.ix + 1];
+      }
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const int xx = c.ix + l;
+        if (xx >= D) continue;
+        float gg = g[l];
+        if (mask) {
+          const float m0 = mask[row + xx];
+          gg = (m0 >= 0.f && m0 <= 1.f) ? gg : 0.f;
+        }
+        drz += gg * (k ? 1.f : -1.f) * wy[j] * wx[l];
+        dry += gg * wz[k] * (j ? 1.f : -1.f) * wx[l];
+        drx += gg * wz[k] * wy[j] * (l ? 1.f : -1.f);
+      }
+    }
+  dw = drz * (float)(Dz - 1);
+  dv = dry * (float)(D - 1);
+  du = drx * (float)(D - 1);
+}
+
+}  // namespace
+
+// ===========================================================================
+// point kernels
+// ===========================================================================
+template <bool QUAT>
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_points_fwd(DpcShape S, DpcParams P, const float* __restrict__ pc, const float* __restrict__ pose,
+             const float* __restrict__ trans, const float* __restrict__ focal,
+             float* __restrict__ tr_pc, float* __restrict__ grid /*nullable*/) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= S.N) return;
+  Pose ps;
+  load_pose<QUAT>(P, pose, trans, focal, b, ps);
+  const size_t o = ((size_t)b * S.N + n) * 3;
+  float w, v, u;
+  transform_point<QUAT>(ps, pc[o], pc[o + 1], pc[o + 2], w, v, u);
+  tr_pc[o] = w;
+  tr_pc[o + 1] = v;
+  tr_pc[o + 2] = u;
+  if (grid) scatter_point(grid, b, S.Dz, S.D, w, v, u);
+}
+
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_scatter(DpcShape S, const float* __restrict__ tr_pc, float* __restrict__ grid) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= S.N) return;
+  const size_t o = ((size_t)b * S.N + n) * 3;
+  scatter_point(grid, b, S.Dz, S.D, tr_pc[o], tr_pc[o + 1], tr_pc[o + 2]);
+}
+
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_gather(DpcShape S, const float* __restrict__ tr_pc, const float* __restrict__ dgrid,
+         float* __restrict__ dtr_pc) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= S.N) return;
+  const size_t o = ((size_t)b * S.N + n) * 3;
+  float dw, dv, du;
+  gather_point(dgrid, nullptr, nullptr, 0, b, S.Dz, S.D, tr_pc[o], tr_pc[o + 1], tr_pc[o + 2], dw, dv, du);
+  dtr_pc[o] = dw;
+  dtr_pc[o + 1] = dv;
+  dtr_pc[o + 2] = du;
+}
+
+// Gather (+ sparse x-blur + clip mask) + camera-transform VJP + per-instance
+// reductions.  GATHER=false: d(tr_pc) is read from dtr_in instead.
+template <bool QUAT, bool GATHER>
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_points_bwd(DpcShape S, DpcParams P, const float* __restrict__ pc, const float* __restrict__ pose,
+             const float* __restrict__ trans, const float* __restrict__ focal,
+             const float* __restrict__ tr_pc, const float* __restrict__ dgrid,
+             const float* __restrict__ mask, const float* __restrict__ taps_x,
+             const float* __restrict__ dtr_in /*nullable when GATHER*/, float* __restrict__ dpc,
+             float* __restrict__ accum /*[B,16], zeroed*/) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if (n < S.N) {
+    Pose ps;
+    load_pose<QUAT>(P, pose, trans, focal, b, ps);
+    const size_t o = ((size_t)b * S.N + n) * 3;
+    float dw = 0.f, dv = 0.f, du = 0.f;
+    if (GATHER)
+      gather_point(dgrid, mask, taps_x, S.Kx, b, S.Dz, S.D, tr_pc[o], tr_pc[o + 1], tr_pc[o + 2], dw, dv, du);
+    if (dtr_in) {
+      dw += dtr_in[o];
+      dv += dtr_in[o + 1];
+      du += dtr_in[o + 2];
+    }
+    float g0, g1, g2;
+    transform_point_bwd<QUAT>(ps, pc[o], pc[o + 1], pc[o + 2], dw, dv, du, g0, g1, g2, acc);
+    dpc[o] = g0;
+    dpc[o + 1] = g1;
+    dpc[o + 2] = g2;
+  }
+  block_reduce_sum<16>(acc);
+  if (threadIdx.x == 0) {
+    const int nacc = QUAT ? 8 : 12;
+    for (int i = 0; i < nacc; ++i) atomicAdd(accum + 16 * b + i, acc[i]);
+  }
+}
+
+template <bool QUAT>
+__global__ void k_pose_finalize(DpcShape S, DpcParams P, const float* __restrict__ pose,
+                                const float* __restrict__ accum, float* __restrict__ dpose,
+                                float* __restrict__ dtrans, float* __restrict__ dfocal) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= S.B) return;
+  const float* a = accum + 16 * b;
+  if (QUAT) {
+    const float* q = pose + 4 * b;
+    const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const float qh[4] = {q[0] / n, q[1] / n, q[2] / n, q[3] / n};
+    const float dot = qh[0] * a[0] + qh[1] * a[1] + qh[2] * a[2] + qh[3] * a[3];
+    for (int i = 0; i < 4; ++i) dpose[4 * b + i] = (a[i] - qh[i] * dot) / n;  // (I - q q^T)/|q|
+    if (dtrans)
+      for (int i = 0; i < 3; ++i) dtrans[3 * b + i] = a[4 + i];
+    if (dfocal) dfocal[b] = a[7];
+  } else {
+    const float f = P.focal_length;
+    for (int j = 0; j < 4; ++j) {
+      dpose[16 * b + 0 + j] = a[0 + j];
+      dpose[16 * b + 4 + j] = f * a[4 + j];
+      dpose[16 * b + 8 + j] = f * a[8 + j];
+      dpose[16 * b + 12 + j] = 0.f;
+    }
+  }
+}
+
+// ===========================================================================
+// plane blur: x then y on a (TY + 2 hy) x D tile staged in LDS
+// ===========================================================================
+// KC > 0: compile-time tap count (both Kx and Ky equal KC when enabled);
+// KC == 0: run-time tap counts (gather form, K LDS reads per output).
+template <int KC>
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_blur_plane(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ taps_x,
+             const float* __restrict__ taps_y, int Kx, int Ky, int Dz, int D, int TY, int nyt, int PA,
+             int PB, int clip_in, int nblocks) {
+  DPC_DYN_SMEM(float, smem);
+  // XCD-aware remap (bijective): consecutive logical tiles (which share halo
+  // rows) stay on one XCD's L2.  Placement only affects speed.
+  int bid = blockIdx.x;
+  {
+    const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, slot = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int yt = bid % nyt;
+  const int pz = bid / nyt;  // = b * Dz + z
+  const int hx = Kx >> 1, hy = Ky >> 1;
+  const int R = TY + 2 * hy;
+  const int y0 = yt * TY;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nwave = nth >> 6;
+  float* A = smem;            // [R][PA]: input tile, x halo of hx zeros each side (+ pad)
+  float* Bm = smem + R * PA;  // [R][PB]: x-blurred tile
+  const float* plane = in + (size_t)pz * D * D;
+
+  // ---- stage 1: global -> LDS (clip fused), zero halos / out-of-range rows
+  for (int r = wave; r < R; r += nwave) {
+    const int gy = y0 - hy + r;
+    const bool rowok = (gy >= 0) && (gy < D);
+    const float* src = plane + (size_t)(rowok ? gy : 0) * D;
+    for (int c = lane; c < PA; c += 64) {
+      const int x = c - hx;
+      float val = 0.f;
+      if (rowok && x >= 0 && x < D) {
+        val = src[x];
+        if (clip_in) val = clampf(val, 0.f, 1.f);
+      }
+      A[r * PA + c] = val;
+    }
+  }
+  __syncthreads();
+
+  // ---- stage 2: x-blur A -> Bm (lanes walk rows: odd pitches => no conflicts)
+  const float* S3 = A;  // source of stage 3
+  int PS = PA;
+  if (Kx > 0) {
+    const int nxc = (D + DPC_XC - 1) / DPC_XC;
+    const float invR = 1.0f / (float)R;
+    for (int item = tid; item < R * nxc; item += nth) {
+      const int xc = fast_div(item, R, invR);
+      const int r = item - xc * R;
+      const float* src = A + r * PA + xc * DPC_XC;
+      float* dst = Bm + r * PB + xc * DPC_XC;
+      if (KC > 0) {
+        float win[DPC_XC + (KC > 0 ? KC : 1) - 1];
+#pragma unroll
+        for (int i = 0; i < DPC_XC + KC - 1; ++i) win[i] = src[i];
+#pragma unroll
+        for (int o = 0; o < DPC_XC; ++o) {
+          float a = 0.f;
+#pragma unroll
+          for (int m = 0; m < KC; ++m) a += taps_x[m] * win[o + m];
+          if (xc * DPC_XC + o < D) dst[o] = a;
+        }
+      } else {
+        for (int o = 0; o < DPC_XC; ++o) {
+          if (xc * DPC_XC + o >= D) break;
+          float a = 0.f;
+          for (int m = 0; m < Kx; ++m) a += taps_x[m] * src[o + m];
+          dst[o] = a;
+        }
+      }
+    }
+    __syncthreads();
+    S3 = Bm;
+    PS = PB;
+  }
+
+  // ---- stage 3: y-blur -> global (lanes walk x: coalesced stores)
+  float* oplane = out + (size_t)pz * D * D;
+  const int nyc = TY / DPC_YC;
+  const float invD = 1.0f / (float)D;
+  for (int item = tid; item < D * nyc; item += nth) {
+    const int yc = fast_div(item, D, invD);
+    const int x = item - yc * D;
+    const float* src = S3 + (yc * DPC_YC) * PS + x;
+    const int gy0 = y0 + yc * DPC_YC;
+    if (Ky > 0) {
+      if (KC > 0) {
+        float win[DPC_YC + (KC > 0 ? KC : 1) - 1];
+#pragma unroll
+        for (int i = 0; i < DPC_YC + KC - 1; ++i) win[i] = src[i * PS];
+#pragma unroll
+        for (int o = 0; o < DPC_YC; ++o) {
+          float a = 0.f;
+#pragma unroll
+          for (int m = 0; m < KC; ++m) a += taps_y[m] * win[o + m];
+          if (gy0 + o < D) oplane[(size_t)(gy0 + o) * D + x] = a;
+        }
+      } else {
+        for (int o = 0; o < DPC_YC; ++o) {
+          if (gy0 + o >= D) break;
+          float a = 0.f;
+          for (int m = 0; m < Ky; ++m) a += taps_y[m] * src[(o + m) * PS];
+          oplane[(size_t)(gy0 + o) * D + x] = a;
+        }
+      }
+    } else {
+      for (int o = 0; o < DPC_YC; ++o)
+        if (gy0 + o < D) oplane[(size_t)(gy0 + o) * D + x] = src[o * PS];
+    }
+  }
+}
+
+// ===========================================================================
+// z streaming kernels: one thread owns CX adjacent rays (y,x .. x+CX-1)
+// ===========================================================================
+template <int CX>
+__device__ __forceinline__ void load_cx(const float* __restrict__ p, float (&v)[CX]) {
+  if (CX == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x;
+    v[1 % CX] = t.y;
+    v[2 % CX] = t.z;
+    v[3 % CX] = t.w;
+  } else if (CX == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x;
+    v[1 % CX] = t.y;
+  } else {
+    v[0] = p[0];
+  }
+}
+template <int CX>
+__device__ __forceinline__ void store_cx(float* __restrict__ p, const float (&v)[CX]) {
+  if (CX == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1 % CX], v[2 % CX], v[3 % CX]);
+  } else if (CX == 2) {
+    *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1 % CX]);
+  } else {
+    p[0] = v[0];
+  }
+}
+
+// Register FIR in "accumulate" form: pushing input plane t completes output
+// plane t - h (zero padding falls out because only real planes are pushed).
+template <int KC, int CX>
+struct ZFir {
+  float acc[KC][CX];
+  float tp[KC];
+  __device__ __forceinline__ void init(const float* __restrict__ taps) {
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      tp[j] = taps ? taps[j] : 1.0f;
+#pragma unroll
+      for (int c = 0; c < CX; ++c) acc[j][c] = 0.f;
+    }
+  }
+  // reversed=true: planes arrive in descending order (adjoint walk)
+  __device__ __forceinline__ void push(const float (&v)[CX], float (&out)[CX], bool reversed) {
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      const float t = reversed ? tp[j] : tp[KC - 1 - j];
+#pragma unroll
+      for (int c = 0; c < CX; ++c) acc[j][c] += t * v[c];
+    }
+#pragma unroll
+    for (int c = 0; c < CX; ++c) out[c] = acc[0][c];
+#pragma unroll
+    for (int j = 0; j + 1 < KC; ++j)
+#pragma unroll
+      for (int c = 0; c < CX; ++c) acc[j][c] = acc[j + 1][c];
+#pragma unroll
+    for (int c = 0; c < CX; ++c) acc[KC - 1][c] = 0.f;
+  }
+};
+
+// plain z blur, compile-time K
+template <int KC, int CX>
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_blur_z(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ taps, int Dz,
+         int D) {
+  const int b = blockIdx.y;
+  const int ncol = D * D;
+  const int col = (blockIdx.x * blockDim.x + threadIdx.x) * CX;
+  if (col >= ncol) return;
+  const size_t base = (size_t)b * Dz * ncol + col;
+  constexpr int h = KC / 2;
+  ZFir<KC, CX> fir;
+  fir.init(taps);
+  for (int t = 0; t < Dz + h; ++t) {
+    float v[CX], o[CX];
+    if (t < Dz) {
+      load_cx<CX>(in + base + (size_t)t * ncol, v);
+    } else {
+#pragma unroll
+      for (int c = 0; c < CX; ++c) v[c] = 0.f;
+    }
+    fir.push(v, o, false);
+    if (t >= h) store_cx<CX>(out + base + (size_t)(t - h) * ncol, o);
+  }
+}
+
+// plain z blur, run-time K (gather form; inputs re-read through L1/L2)
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_blur_z_generic(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ taps,
+                 int K, int Dz, int D) {
+  const int b = blockIdx.y;
+  const int ncol = D * D;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncol) return;
+  const size_t base = (size_t)b * Dz * ncol + col;
+  const int h = K >> 1;
+  for (int o = 0; o < Dz; ++o) {
+    float a = 0.f;
+    for (int m = 0; m < K; ++m) {
+      const int z = o + m - h;
+      if (z >= 0 && z < Dz) a += taps[m] * in[base + (size_t)z * ncol];
+    }
+    out[base + (size_t)o * ncol] = a;
+  }
+}
+
+// Forward: z-FIR + (scale, clip) + log-space DRC collapse (drc.py:47-123) +
+// depth (drc.py:139-153), streaming each ray once.
+//   in      xy-blurred grid (or raw grid with clip_in when there is no blur)
+//   g2_out  post-blur grid G2, saved for backward            (nullable)
+//   probs   event probabilities [Dz+1,B,D,D]                 (nullable)
+//   proj/depth [B,D,D] (flip_h: image row D-1-y); logt [B,D,D] double, row y
+template <int KC, int CX>
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps,
+       const float* __restrict__ scale, float* __restrict__ g2_out, float* __restrict__ probs,
+       float* __restrict__ proj, float* __restrict__ depth, double* __restrict__ logt, int B, int Dz,
+       int D, int clip_in, int flip_h) {
+  const int b = blockIdx.y;
+  const int ncol = D * D;
+  const int col = (blockIdx.x * blockDim.x + threadIdx.x) * CX;
+  if (col >= ncol) return;
+  const size_t base = (size_t)b * Dz * ncol + col;
+  const int y = col / D, x0 = col - y * D;
+  const int ocol = (flip_h ? (D - 1 - y) : y) * D + x0;
+  constexpr int h = KC / 2;
+  const float eps = P.eps, one_m = 1.0f - P.eps;
+  const bool has_s = scale != nullptr;
+  const float s = has_s ? scale[b] : 1.0f;
+  const float fDz = (float)Dz;
+  ZFir<KC, CX> fir;
+  fir.init(taps);
+  float S[CX], pj[CX], dp[CX];
+  double Sd[CX];
+#pragma unroll
+  for (int c = 0; c < CX; ++c) {
+    S[c] = 0.f;
+    pj[c] = 0.f;
+    dp[c] = 0.f;
+    Sd[c] = 0.0;
+  }
+  for (int t = 0; t < Dz + h; ++t) {
+    float v[CX], g2[CX];
+    if (t < Dz) {
+      load_cx<CX>(in + base + (size_t)t * ncol, v);
+      if (clip_in) {
+#pragma unroll
+        for (int c = 0; c < CX; ++c) v[c] = clampf(v[c], 0.f, 1.f);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CX; ++c) v[c] = 0.f;
+    }
+    fir.push(v, g2, false);
+    if (t < h) continue;
+    const int o = t - h;
+    if (g2_out) store_cx<CX>(g2_out + base + (size_t)o * ncol, g2);
+    const float psi = (float)o / fDz - 0.5f + P.camera_distance;
+    float pv[CX];
+#pragma unroll
+    for (int c = 0; c < CX; ++c) {
+      const float g3 = has_s ? clampf(g2[c] * s, 0.f, 1.f) : g2[c];
+      const float cc = clampf(g3, eps, one_m);
+      const float ly = logf(cc);
+      const float lx = logf(1.0f - cc);
+      const float p = expf((o == 0 ? eps : S[c]) + ly);  // "unity" is eps (drc.py:58-59)
+      pv[c] = p;
+      pj[c] += p;
+      dp[c] += p * psi;
+      S[c] += lx;
+      Sd[c] += (double)lx;
+    }
+    if (probs) store_cx<CX>(probs + ((size_t)o * B + b) * ncol + ocol, pv);
+  }
+  float pl[CX];
+#pragma unroll
+  for (int c = 0; c < CX; ++c) {
+    pl[c] = expf(S[c] + eps);
+    dp[c] += pl[c] * P.max_depth;
+  }
+  if (probs) store_cx<CX>(probs + ((size_t)Dz * B + b) * ncol + ocol, pl);
+  if (proj) store_cx<CX>(proj + (size_t)b * ncol + ocol, pj);
+  if (depth) store_cx<CX>(depth + (size_t)b * ncol + ocol, dp);
+  if (logt) {
+#pragma unroll
+    for (int c = 0; c < CX; ++c) logt[(size_t)b * ncol + col + c] = Sd[c];
+  }
+}
+
+// Backward: walks each ray from far to near.  With gamma_i = dL/dp_i,
+// a_i = gamma_i p_i:  dL/dc_j = a_j/c_j - (sum_{i>j} a_i)/(1-c_j), masked by
+// eps <= G3_j <= 1-eps; then the scale/clip mask, dscale, and the z-FIR
+// adjoint.  S_j = logT - sum_{i>=j} log(1-c_i) is formed in fp64 so that no
+// precision is lost to the subtraction.  logt == null => an ascending
+// pre-pass recomputes it.
+template <int KC, int CX>
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ taps,
+       const float* __restrict__ scale, const double* __restrict__ logt,
+       const float* __restrict__ dproj, const float* __restrict__ ddepth,
+       const float* __restrict__ dprobs, float* __restrict__ dgz, float* __restrict__ dscale, int B,
+       int Dz, int D, int flip_h) {
+  const int b = blockIdx.y;
+  const int ncol = D * D;
+  const int col = (blockIdx.x * blockDim.x + threadIdx.x) * CX;
+  const bool active = col < ncol;
+  float dsacc[1] = {0.f};
+  if (active) {
+    const size_t base = (size_t)b * Dz * ncol + col;
+    const int y = col / D, x0 = col - y * D;
+    const int ocol = (flip_h ? (D - 1 - y) : y) * D + x0;
+    constexpr int h = KC / 2;
+    const float eps = P.eps, one_m = 1.0f - P.eps;
+    const bool has_s = scale != nullptr;
+    const float s = has_s ? scale[b] : 1.0f;
+    const float fDz = (float)Dz;
+    float g[CX], gd[CX], suffix[CX];
+    double St[CX], R[CX];
+#pragma unroll
+    for (int c = 0; c < CX; ++c) {
+      g[c] = dproj ? dproj[(size_t)b * ncol + ocol + c] : 0.f;
+      gd[c] = ddepth ? ddepth[(size_t)b * ncol + ocol + c] : 0.f;
+      R[c] = 0.0;
+    }
+    if (logt) {
+#pragma unroll
+      for (int c = 0; c < CX; ++c) St[c] = logt[(size_t)b * ncol + col + c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < CX; ++c) St[c] = 0.0;
+      for (int j = 0; j < Dz; ++j) {
+        float v[CX];
+        load_cx<CX>(g2_in + base + (size_t)j * ncol, v);
+#pragma unroll
+        for (int c = 0; c < CX; ++c) {
+          const float g3 = has_s ? clampf(v[c] * s, 0.f, 1.f) : v[c];
+          const float cc = clampf(g3, eps, one_m);
+          St[c] += (double)logf(1.0f - cc);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CX; ++c) {
+      float gl = gd[c] * P.max_depth;
+      if (dprobs) gl += dprobs[((size_t)Dz * B + b) * ncol + ocol + c];
+      suffix[c] = gl * expf((float)St[c] + eps);  // a_Dz
+    }
+    ZFir<KC, CX> fir;
+    fir.init(taps);
+    for (int t = 0; t < Dz + h; ++t) {
+      const int j = Dz - 1 - t;
+      float dg2[CX], o[CX];
+      if (j >= 0) {
+        float v[CX];
+        load_cx<CX>(g2_in + base + (size_t)j * ncol, v);
+        const float psi = (float)j / fDz - 0.5f + P.camera_distance;
+#pragma unroll
+        for (int c = 0; c < CX; ++c) {
+          const float sg = v[c] * s;
+          const float g3 = has_s ? clampf(sg, 0.f, 1.f) : v[c];
+          const float cc = clampf(g3, eps, one_m);
+          const float ly = logf(cc);
+          const float omc = 1.0f - cc;
+          const float lx = logf(omc);
+          R[c] += (double)lx;
+          const float Sj = (float)(St[c] - R[c]);
+          const float p = expf((j == 0 ? eps : Sj) + ly);
+          float gam = g[c] + gd[c] * psi;
+          if (dprobs) gam += dprobs[((size_t)j * B + b) * ncol + ocol + c];
+          const float a = gam * p;
+          const float dc = a / cc - suffix[c] / omc;
+          const float dg3 = (g3 >= eps && g3 <= one_m) ? dc : 0.f;
+          suffix[c] += a;
+          if (has_s) {
+            const bool m2 = (sg >= 0.f) && (sg <= 1.f);
+            dg2[c] = m2 ? s * dg3 : 0.f;
+            dsacc[0] += m2 ? v[c] * dg3 : 0.f;
+          } else {
+            dg2[c] = dg3;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CX; ++c) dg2[c] = 0.f;
+      }
+      fir.push(dg2, o, true);
+      if (t >= h) store_cx<CX>(dgz + base + (size_t)(j + h) * ncol, o);
+    }
+  }
+  if (dscale) {  // uniform across the grid
+    block_reduce_sum<1>(dsacc);
+    if (threadIdx.x == 0) atomicAdd(dscale + b, dsacc[0]);
+  }
+}
+
+// tf.reduce_max over z (point_cloud.py:264-267) and its tie-sharing gradient
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_max_fwd(const float* __restrict__ vox, const float* __restrict__ scale, float* __restrict__ proj,
+          int Dz, int D, int flip_h) {
+  const int b = blockIdx.y;
+  const int ncol = D * D;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncol) return;
+  const size_t base = (size_t)b * Dz * ncol + col;
+  const bool has_s = scale != nullptr;
+  const float s = has_s ? scale[b] : 1.0f;
+  float m = -INFINITY;
+  for (int j = 0; j < Dz; ++j) {
+    const float v = vox[base + (size_t)j * ncol];
+    m = fmaxf(m, has_s ? clampf(v * s, 0.f, 1.f) : v);
+  }
+  const int y = col / D, x = col - y * D;
+  proj[(size_t)b * ncol + (flip_h ? (D - 1 - y) : y) * D + x] = m;
+}
+
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_max_bwd(const float* __restrict__ vox, const float* __restrict__ scale,
+          const float* __restrict__ dproj, float* __restrict__ dvox, float* __restrict__ dscale, int Dz,
+          int D, int flip_h) {
+  const int b = blockIdx.y;
+  const int ncol = D * D;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  float dsacc[1] = {0.f};
+  if (col < ncol) {
+    const size_t base = (size_t)b * Dz * ncol + col;
+    const bool has_s = scale != nullptr;
+    const float s = has_s ? scale[b] : 1.0f;
+    float m = -INFINITY;
+    for (int j = 0; j < Dz; ++j) {
+      const float v = vox[base + (size_t)j * ncol];
+      m = fmaxf(m, has_s ? clampf(v * s, 0.f, 1.f) : v);
+    }
+    int cnt = 0;
+    for (int j = 0; j < Dz; ++j) {
+      const float v = vox[base + (size_t)j * ncol];
+      cnt += ((has_s ? clampf(v * s, 0.f, 1.f) : v) == m) ? 1 : 0;
+    }
+    const int y = col / D, x = col - y * D;
+    const float g = dproj[(size_t)b * ncol + (flip_h ? (D - 1 - y) : y) * D + x] / (float)cnt;
+    for (int j = 0; j < Dz; ++j) {
+      const float v = vox[base + (size_t)j * ncol];
+      const float sg = v * s;
+      const float g3 = has_s ? clampf(sg, 0.f, 1.f) : v;
+      float d = (g3 == m) ? g : 0.f;
+      if (has_s) {
+        const bool m2 = (sg >= 0.f) && (sg <= 1.f);
+        dsacc[0] += m2 ? v * d : 0.f;
+        d = m2 ? s * d : 0.f;
+      }
+      dvox[base + (size_t)j * ncol] = d;
+    }
+  }
+  if (dscale) {
+    block_reduce_sum<1>(dsacc);
+    if (threadIdx.x == 0) atomicAdd(dscale + b, dsacc[0]);
+  }
+}
+
+// ===========================================================================
+// host side: validation, launch geometry, C ABI
+// ===========================================================================
+namespace {
+
+int check_shape(const DpcShape* S, bool need_points) {
+  if (!S) return DPC_E_NULL;
+  if (S->B <= 0 || S->Dz <= 0 || S->D <= 0 || S->B > 65535) return DPC_E_SHAPE;
+  if (need_points && S->N <= 0) return DPC_E_SHAPE;
+  if ((long long)S->D * S->D > (1 << 20) || S->Dz > 4096) return DPC_E_SHAPE;
+  const int ks[3] = {S->Kx, S->Ky, S->Kz};
+  for (int i = 0; i < 3; ++i) {
+    if (ks[i] < 0 || ks[i] > DPC_MAX_TAPS) return DPC_E_TAPS;
+    if (ks[i] > 0 && (ks[i] % 2) == 0) return DPC_E_TAPS;
+  }
+  return DPC_OK;
+}
+
+inline size_t grid_elems(const DpcShape& S) { return (size_t)S.B * S.Dz * S.D * S.D; }
+inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+inline int last_error() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? DPC_OK : (int)e;
+}
+
+inline dim3 point_grid(const DpcShape& S) { return dim3((S.N + DPC_BLOCK - 1) / DPC_BLOCK, S.B, 1); }
+
+// ---- plane blur launch -------------------------------------------------------
+int launch_blur_plane(hipStream_t st, const DpcShape& S, const float* in, float* out, const float* tx,
+                      const float* ty, int Kx, int Ky, int clip_in) {
+  const int D = S.D;
+  const int hx = Kx / 2, hy = Ky / 2;
+  const int nxc = (D + DPC_XC - 1) / DPC_XC;
+  int PA = nxc * DPC_XC + 2 * hx;
+  if ((PA & 1) == 0) PA += 1;
+  const int PB = D | 1;
+  int TY = 32;
+  size_t bytes = 0;
+  for (;;) {
+    const int R = TY + 2 * hy;
+    bytes = sizeof(float) * ((size_t)R * PA + (Kx > 0 ? (size_t)R * PB : 0));
+    if (bytes <= 60 * 1024 || TY == DPC_YC) break;
+    TY >>= 1;
+  }
+  if (bytes > 64 * 1024) return DPC_E_SHAPE;
+  const int nyt = (D + TY - 1) / TY;
+  const long long nblocks = (long long)S.B * S.Dz * nyt;
+  if (nblocks > 0x7fffffffLL) return DPC_E_SHAPE;
+  const dim3 grid((unsigned)nblocks, 1, 1), block(DPC_BLOCK, 1, 1);
+  const bool fixed_ok = (Kx == 0 || Ky == 0 || Kx == Ky);
+  const int K = Kx > 0 ? Kx : Ky;
+#define DPC_PLANE_CASE(KC)                                                                          \
+  DPC_LAUNCH((k_blur_plane<KC>), grid, block, bytes, st, in, out, tx, ty, Kx, Ky, S.Dz, D, TY, nyt, \
+             PA, PB, clip_in, (int)nblocks)
+  if (fixed_ok && K == 5) {
+    DPC_PLANE_CASE(5);
+  } else if (fixed_ok && K == 11) {
+    DPC_PLANE_CASE(11);
+  } else if (fixed_ok && K == 21) {
+    DPC_PLANE_CASE(21);
+  } else {
+    DPC_PLANE_CASE(0);
+  }
+#undef DPC_PLANE_CASE
+  return last_error();
+}
+
+inline int pick_cx(int D) { return ((D * D) % 2 == 0 && D % 2 == 0) ? 2 : 1; }
+inline dim3 col_grid(const DpcShape& S, int cx) {
+  const int nthr = (S.D * S.D + cx - 1) / cx;
+  return dim3((nthr + DPC_BLOCK - 1) / DPC_BLOCK, S.B, 1);
+}
+inline bool z_fixed(int K) { return K == 0 || K == 3 || K == 5 || K == 7 || K == 9 || K == 11 || K == 21; }
+
+#define DPC_Z_DISPATCH(K, CX, MACRO) \
+  do {                               \
+    const int k_ = (K) == 0 ? 1 : (K); \
+    if (CX == 2) {                   \
+      switch (k_) {                  \
+        case 1: MACRO(1, 2); break;  \
+        case 3: MACRO(3, 2); break;  \
+        case 5: MACRO(5, 2); break;  \
+        case 7: MACRO(7, 2); break;  \
+        case 9: MACRO(9, 2); break;  \
+        case 11: MACRO(11, 2); break; \
+        case 21: MACRO(21, 2); break; \
+      }                              \
+    } else {                         \
+      switch (k_) {                  \
+        case 1: MACRO(1, 1); break;  \
+        case 3: MACRO(3, 1); break;  \
+        case 5: MACRO(5, 1); break;  \
+        case 7: MACRO(7, 1); break;  \
+        case 9: MACRO(9, 1); break;  \
+        case 11: MACRO(11, 1); break; \
+        case 21: MACRO(21, 1); break; \
+      }                              \
+    }                                \
+  } while (0)
+
+int launch_blur_z(hipStream_t st, const DpcShape& S, const float* in, float* out, const float* tz, int Kz) {
+  const dim3 block(DPC_BLOCK, 1, 1);
+  if (z_fixed(Kz) && Kz > 0) {
+    const int cx = pick_cx(S.D);
+    const dim3 grid = col_grid(S, cx);
+#define DPC_M(KC, CXV) DPC_LAUNCH((k_blur_z<KC, CXV>), grid, block, 0, st, in, out, tz, S.Dz, S.D)
+    DPC_Z_DISPATCH(Kz, cx, DPC_M);
+#undef DPC_M
+  } else {
+    DPC_LAUNCH((k_blur_z_generic), col_grid(S, 1), block, 0, st, in, out, tz, Kz, S.Dz, S.D);
+  }
+  return last_error();
+}
+
+// in -> (z-FIR Kz) -> collapse.  Kz must be z_fixed().
+int launch_zfwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const float* in, const float* tz,
+                int Kz, const float* scale, float* g2_out, float* probs, float* proj, float* depth,
+                double* logt, int clip_in, int flip_h) {
+  const dim3 block(DPC_BLOCK, 1, 1);
+  const int cx = pick_cx(S.D);
+  const dim3 grid = col_grid(S, cx);
+#define DPC_M(KC, CXV)                                                                                \
+  DPC_LAUNCH((k_zfwd<KC, CXV>), grid, block, 0, st, P, in, (Kz > 0 ? tz : (const float*)nullptr), scale, \
+             g2_out, probs, proj, depth, logt, S.B, S.Dz, S.D, clip_in, flip_h)
+  DPC_Z_DISPATCH(Kz, cx, DPC_M);
+#undef DPC_M
+  return last_error();
+}
+
+int launch_zbwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const float* g2, const float* tz,
+                int Kz, const float* scale, const double* logt, const float* dproj, const float* ddepth,
+                const float* dprobs, float* dgz, float* dscale, int flip_h) {
+  const dim3 block(DPC_BLOCK, 1, 1);
+  const int cx = pick_cx(S.D);
+  const dim3 grid = col_grid(S, cx);
+#define DPC_M(KC, CXV)                                                                                \
+  DPC_LAUNCH((k_zbwd<KC, CXV>), grid, block, 0, st, P, g2, (Kz > 0 ? tz : (const float*)nullptr), scale, \
+             logt, dproj, ddepth, dprobs, dgz, dscale, S.B, S.Dz, S.D, flip_h)
+  DPC_Z_DISPATCH(Kz, cx, DPC_M);
+#undef DPC_M
+  return last_error();
+}
+
+int launch_points_bwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const float* pc,
+                      const float* pose, const float* trans, const float* focal, const float* tr_pc,
+                      const float* dgrid, const float* mask, const float* taps_x, const float* dtr_in,
+                      bool gather, float* dpc, float* dpose, float* dtrans, float* dfocal, float* accum) {
+  hipError_t e = hipMemsetAsync(accum, 0, sizeof(float) * 16 * (size_t)S.B, st);
+  if (e != hipSuccess) return (int)e;
+  const dim3 grid = point_grid(S), block(DPC_BLOCK, 1, 1);
+  const bool quat = P.pose_is_quaternion != 0;
+#define DPC_PB(Q, G)                                                                                  \
+  DPC_LAUNCH((k_points_bwd<Q, G>), grid, block, 0, st, S, P, pc, pose, trans, focal, tr_pc, dgrid, mask, \
+             taps_x, dtr_in, dpc, accum)
+  if (quat && gather) DPC_PB(true, true);
+  else if (quat) DPC_PB(true, false);
+  else if (gather) DPC_PB(false, true);
+  else DPC_PB(false, false);
+#undef DPC_PB
+  const dim3 fg((S.B + 63) / 64, 1, 1), fb(64, 1, 1);
+  if (quat)
+    DPC_LAUNCH((k_pose_finalize<true>), fg, fb, 0, st, S, P, pose, accum, dpose, dtrans, dfocal);
+  else
+    DPC_LAUNCH((k_pose_finalize<false>), fg, fb, 0, st, S, P, pose, accum, dpose, dtrans, dfocal);
+  return last_error();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dpc_version(void) { return "dpc_hip 0.1.0 (gfx950)"; }
+
+size_t dpc_workspace_bytes(const DpcShape* shape, int direction) {
+  if (check_shape(shape, false) != DPC_OK) return 0;
+  const size_t g = align256(grid_elems(*shape) * sizeof(float));
+  const size_t acc = align256(sizeof(float) * 16 * (size_t)shape->B);
+  return direction == 0 ? g : 2 * g + acc;
+}
+
+int dpc_transform_fwd(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* pc,
+                      const float* pose, const float* trans, const float* focal, float* tr_pc) {
+  int rc = check_shape(shape, true);
+  if (rc) return rc;
+  if (!params || !pc || !pose || !tr_pc) return DPC_E_NULL;
+  if (!params->pose_is_quaternion && trans) return DPC_E_MODE;  // point_cloud.py:211-213
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid = point_grid(*shape), block(DPC_BLOCK, 1, 1);
+  if (params->pose_is_quaternion)
+    DPC_LAUNCH((k_points_fwd<true>), grid, block, 0, st, *shape, *params, pc, pose, trans, focal, tr_pc,
+               (float*)nullptr);
+  else
+    DPC_LAUNCH((k_points_fwd<false>), grid, block, 0, st, *shape, *params, pc, pose, trans, focal, tr_pc,
+               (float*)nullptr);
+  return last_error();
+}
+
+int dpc_transform_bwd(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* pc,
+                      const float* pose, const float* trans, const float* focal, const float* dtr_pc,
+                      float* dpc, float* dpose, float* dtrans, float* dfocal, float* scratch) {
+  int rc = check_shape(shape, true);
+  if (rc) return rc;
+  if (!params || !pc || !pose || !dtr_pc || !dpc || !dpose || !scratch) return DPC_E_NULL;
+  if (!params->pose_is_quaternion && trans) return DPC_E_MODE;
+  return launch_points_bwd((hipStream_t)stream, *shape, *params, pc, pose, trans, focal, nullptr, nullptr,
+                           nullptr, nullptr, dtr_pc, false, dpc, dpose, dtrans, dfocal, scratch);
+}
+
+int dpc_voxelize_fwd(dpc_stream_t stream, const DpcShape* shape, const float* tr_pc, float* grid) {
+  int rc = check_shape(shape, true);
+  if (rc) return rc;
+  if (!tr_pc || !grid) return DPC_E_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(grid, 0, grid_elems(*shape) * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  DPC_LAUNCH((k_scatter), point_grid(*shape), dim3(DPC_BLOCK, 1, 1), 0, st, *shape, tr_pc, grid);
+  return last_error();
+}
+
+int dpc_voxelize_bwd(dpc_stream_t stream, const DpcShape* shape, const float* tr_pc, const float* dgrid,
+                     float* dtr_pc) {
+  int rc = check_shape(shape, true);
+  if (rc) return rc;
+  if (!tr_pc || !dgrid || !dtr_pc) return DPC_E_NULL;
+  DPC_LAUNCH((k_gather), point_grid(*shape), dim3(DPC_BLOCK, 1, 1), 0, (hipStream_t)stream, *shape, tr_pc,
+             dgrid, dtr_pc);
+  return last_error();
+}
+
+int dpc_blur3d(dpc_stream_t stream, const DpcShape* shape, const float* in, float* out, const float* taps_x,
+               const float* taps_y, const float* taps_z, float* tmp, int order) {
+  int rc = check_shape(shape, false);
+  if (rc) return rc;
+  if (!in || !out || in == out) return DPC_E_NULL;
+  const DpcShape& S = *shape;
+  if ((S.Kx > 0 && !taps_x) || (S.Ky > 0 && !taps_y) || (S.Kz > 0 && !taps_z)) return DPC_E_NULL;
+  const bool plane = S.Kx > 0 || S.Ky > 0, zed = S.Kz > 0;
+  if (!plane && !zed) return DPC_E_TAPS;
+  if (plane && zed && !tmp) return DPC_E_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  if (plane && zed) {
+    if (order == 0) {
+      rc = launch_blur_plane(st, S, in, tmp, taps_x, taps_y, S.Kx, S.Ky, 0);
+      if (rc) return rc;
+      return launch_blur_z(st, S, tmp, out, taps_z, S.Kz);
+    }
+    rc = launch_blur_z(st, S, in, tmp, taps_z, S.Kz);
+    if (rc) return rc;
+    return launch_blur_plane(st, S, tmp, out, taps_x, taps_y, S.Kx, S.Ky, 0);
+  }
+  if (plane) return launch_blur_plane(st, S, in, out, taps_x, taps_y, S.Kx, S.Ky, 0);
+  return launch_blur_z(st, S, in, out, taps_z, S.Kz);
+}
+
+int dpc_drc_fwd(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* voxels,
+                float* proj, float* probs, int flip_h) {
+  int rc = check_shape(shape, false);
+  if (rc) return rc;
+  if (!params || !voxels || !proj) return DPC_E_NULL;
+  return launch_zfwd((hipStream_t)stream, *shape, *params, voxels, nullptr, 0, nullptr, nullptr, probs, proj,
+                     nullptr, nullptr, 0, flip_h);
+}
+
+int dpc_drc_bwd(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* voxels,
+                const float* dproj, const float* dprobs, float* dvoxels, int flip_h) {
+  int rc = check_shape(shape, false);
+  if (rc) return rc;
+  if (!params || !voxels || !dvoxels || (!dproj && !dprobs)) return DPC_E_NULL;
+  return launch_zbwd((hipStream_t)stream, *shape, *params, voxels, nullptr, 0, nullptr, nullptr, dproj,
+                     nullptr, dprobs, dvoxels, nullptr, flip_h);
+}
+
+int dpc_max_collapse_fwd(dpc_stream_t stream, const DpcShape* shape, const float* voxels, float* proj,
+                         int flip_h) {
+  int rc = check_shape(shape, false);
+  if (rc) return rc;
+  if (!voxels || !proj) return DPC_E_NULL;
+  DPC_LAUNCH((k_max_fwd), col_grid(*shape, 1), dim3(DPC_BLOCK, 1, 1), 0, (hipStream_t)stream, voxels,
+             (const float*)nullptr, proj, shape->Dz, shape->D, flip_h);
+  return last_error();
+}
+
+int dpc_max_collapse_bwd(dpc_stream_t stream, const DpcShape* shape, const float* voxels, const float* dproj,
+                         float* dvoxels, int flip_h) {
+  int rc = check_shape(shape, false);
+  if (rc) return rc;
+  if (!voxels || !dproj || !dvoxels) return DPC_E_NULL;
+  DPC_LAUNCH((k_max_bwd), col_grid(*shape, 1), dim3(DPC_BLOCK, 1, 1), 0, (hipStream_t)stream, voxels,
+             (const float*)nullptr, dproj, dvoxels, (float*)nullptr, shape->Dz, shape->D, flip_h);
+  return last_error();
+}
+
+int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* pc,
+                        const float* pose, const float* trans, const float* scale, const float* focal,
+                        const float* taps_x, const float* taps_y, const float* taps_z, float* tr_pc,
+                        float* grid_raw, float* grid_blur, double* ray_logt, float* proj, float* proj_depth,
+                        void* workspace, size_t workspace_bytes) {
+  int rc = check_shape(shape, true);
+  if (rc) return rc;
+  if (!params || !pc || !pose || !tr_pc || !grid_raw || !grid_blur || !proj) return DPC_E_NULL;
+  const DpcShape& S = *shape;
+  const DpcParams& P = *params;
+  if ((S.Kx > 0 && !taps_x) || (S.Ky > 0 && !taps_y) || (S.Kz > 0 && !taps_z)) return DPC_E_NULL;
+  if (!P.pose_is_quaternion && trans) return DPC_E_MODE;
+  const bool drc = P.collapse_mode == DPC_COLLAPSE_DRC;
+  if (!drc && P.collapse_mode != DPC_COLLAPSE_MAX) return DPC_E_MODE;
+  if (drc && !ray_logt) return DPC_E_NULL;
+  const bool plane = S.Kx > 0 || S.Ky > 0;
+  if (plane && (!workspace || workspace_bytes < dpc_workspace_bytes(shape, 0) ||
+                ((uintptr_t)workspace & 255) != 0))
+    return DPC_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* tmp = (float*)workspace;
+
+  // 1. zero G0, transform + scatter
+  hipError_t e = hipMemsetAsync(grid_raw, 0, grid_elems(S) * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  {
+    const dim3 grid = point_grid(S), block(DPC_BLOCK, 1, 1);
+    if (P.pose_is_quaternion)
+      DPC_LAUNCH((k_points_fwd<true>), grid, block, 0, st, S, P, pc, pose, trans, focal, tr_pc, grid_raw);
+    else
+      DPC_LAUNCH((k_points_fwd<false>), grid, block, 0, st, S, P, pc, pose, trans, focal, tr_pc, grid_raw);
+    rc = last_error();
+    if (rc) return rc;
+  }
+  // 2. clip + x,y blur (LDS tiles)
+  const float* zin = grid_raw;
+  int clip_in = 1;
+  if (plane) {
+    rc = launch_blur_plane(st, S, grid_raw, tmp, taps_x, taps_y, S.Kx, S.Ky, 1);
+    if (rc) return rc;
+    zin = tmp;
+    clip_in = 0;
+  }
+  // 3. z blur fused with the ray collapse
+  if (drc && z_fixed(S.Kz))
+    return launch_zfwd(st, S, P, zin, taps_z, S.Kz, scale, grid_blur, nullptr, proj, proj_depth, ray_logt,
+                       clip_in, 1);
+  // generic tap count or max-collapse: materialise G2, then collapse separately
+  if (S.Kz > 0) {
+    if (clip_in) return DPC_E_MODE;  // z-only blur of the raw grid is not a reference configuration
+    rc = launch_blur_z(st, S, zin, grid_blur, taps_z, S.Kz);
+    if (rc) return rc;
+    zin = grid_blur;
+  }
+  if (drc) {
+    // G2 already in grid_blur (or still the unblurred grid): collapse with a K=1 pass
+    return launch_zfwd(st, S, P, zin, nullptr, 0, scale, (zin == grid_blur ? nullptr : grid_blur), nullptr,
+                       proj, proj_depth, ray_logt, clip_in, 1);
+  }
+  if (zin != grid_blur) {  // no z blur: G2 = (clipped) input; copy through the K=1 FIR kernel
+    const int cx = pick_cx(S.D);
+    (void)cx;
+    rc = launch_zfwd(st, S, P, zin, nullptr, 0, nullptr, grid_blur, nullptr, nullptr, nullptr, nullptr,
+                     clip_in, 1);
+    if (rc) return rc;
+  }
+  DPC_LAUNCH((k_max_fwd), col_grid(S, 1), dim3(DPC_BLOCK, 1, 1), 0, st, (const float*)grid_blur, scale, proj,
+             S.Dz, S.D, 1);
+  return last_error();
+}
+
+int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* pc,
+                         const float* pose, const float* trans, const float* scale, const float* focal,
+                         const float* taps_x, const float* taps_y, const float* taps_z, const float* tr_pc,
+                         const float* grid_raw, const float* grid_blur, const double* ray_logt,
+                         const float* dproj, const float* dproj_depth, const float* dtr_pc_in, float* dpc,
+                         float* dpose, float* dtrans, float* dscale, float* dfocal, void* workspace,
+                         size_t workspace_bytes) {
+  int rc = check_shape(shape, true);
+  if (rc) return rc;
+  if (!params || !pc || !pose || !tr_pc || !grid_raw || !grid_blur || !dpc || !dpose) return DPC_E_NULL;
+  const DpcShape& S = *shape;
+  const DpcParams& P = *params;
+  if ((S.Kx > 0 && !taps_x) || (S.Ky > 0 && !taps_y) || (S.Kz > 0 && !taps_z)) return DPC_E_NULL;
+  if (!P.pose_is_quaternion && trans) return DPC_E_MODE;
+  const bool drc = P.collapse_mode == DPC_COLLAPSE_DRC;
+  if (!drc && P.collapse_mode != DPC_COLLAPSE_MAX) return DPC_E_MODE;
+  if (!dproj && !(drc && dproj_depth)) return DPC_E_NULL;
+  if (scale && !dscale) return DPC_E_NULL;
+  if (!workspace || workspace_bytes < dpc_workspace_bytes(shape, 1) || ((uintptr_t)workspace & 255) != 0)
+    return DPC_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t gbytes = align256(grid_elems(S) * sizeof(float));
+  float* tA = (float*)workspace;
+  float* tB = (float*)((char*)workspace + gbytes);
+  float* accum = (float*)((char*)workspace + 2 * gbytes);
+
+  if (dscale) {
+    hipError_t e = hipMemsetAsync(dscale, 0, sizeof(float) * (size_t)S.B, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  // 1. collapse VJP (+ z-FIR adjoint) -> tA
+  if (drc && z_fixed(S.Kz)) {
+    rc = launch_zbwd(st, S, P, grid_blur, taps_z, S.Kz, scale, ray_logt, dproj, dproj_depth, nullptr, tA,
+                     dscale, 1);
+    if (rc) return rc;
+  } else {
+    float* first = (S.Kz > 0) ? tB : tA;
+    if (drc) {
+      rc = launch_zbwd(st, S, P, grid_blur, nullptr, 0, scale, ray_logt, dproj, dproj_depth, nullptr, first,
+                       dscale, 1);
+    } else {
+      DPC_LAUNCH((k_max_bwd), col_grid(S, 1), dim3(DPC_BLOCK, 1, 1), 0, st, grid_blur, scale, dproj, first,
+                 dscale, S.Dz, S.D, 1);
+      rc = last_error();
+    }
+    if (rc) return rc;
+    if (S.Kz > 0) {
+      rc = launch_blur_z(st, S, tB, tA, taps_z, S.Kz);
+      if (rc) return rc;
+    }
+  }
+  // 2. y-blur adjoint (dense) -> tB ; the x-blur is evaluated sparsely in step 3
+  const float* dg = tA;
+  if (S.Ky > 0) {
+    rc = launch_blur_plane(st, S, tA, tB, nullptr, taps_y, 0, S.Ky, 0);
+    if (rc) return rc;
+    dg = tB;
+  }
+  // 3. sparse x-blur + clip mask + gather + transform VJP + reductions
+  return launch_points_bwd(st, S, P, pc, pose, trans, focal, tr_pc, dg, grid_raw, taps_x, dtr_pc_in, true,
+                           dpc, dpose, dtrans, dfocal, accum);
+}
+
+}  // extern "C"

@@ -1,0 +1,358 @@
+"""torch.autograd plumbing over the C ABI (include/dpc_hip.h).
+
+PyTorch is used for device memory, the current HIP stream and autograd
+bookkeeping only; every number is produced by the hand-written kernels in
+csrc/dpc_kernels.hip.  Tensors must be float32 on a ROCm device.
+"""
+import collections
+import ctypes
+
+import torch
+
+from . import _capi
+from ._capi import DpcParams, DpcShape
+
+ProjMeta = collections.namedtuple(
+    "ProjMeta", "Dz D camera_distance focal_length eps max_depth pose_quaternion collapse_mode")
+
+
+# ---------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------
+def _lib_for(*tensors):
+    lib = _capi.get_library()
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("expected a torch.Tensor, got %r" % type(t))
+        if t.dtype != torch.float32:
+            raise TypeError("the projector computes in float32; got %s" % t.dtype)
+        if lib.host_memory:
+            if t.is_cuda:
+                raise ValueError("emulation library needs host tensors")
+        elif not t.is_cuda:
+            raise ValueError("the HIP projector needs tensors on a ROCm device (no CPU fallback)")
+    devs = {t.device for t in tensors if t is not None}
+    if len(devs) > 1:
+        raise ValueError("tensors on different devices: %s" % sorted(map(str, devs)))
+    return lib
+
+
+def _stream(lib, ref):
+    if lib.host_memory:
+        return None
+    return ctypes.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _c(t):
+    return None if t is None else t.detach().contiguous()
+
+
+def _shape(B, N, meta, K=(0, 0, 0)):
+    return DpcShape(int(B), int(N), int(meta.Dz), int(meta.D), int(K[0]), int(K[1]), int(K[2]))
+
+
+def _params(meta):
+    return DpcParams(float(meta.camera_distance), float(meta.focal_length), float(meta.eps),
+                     float(meta.max_depth), 1 if meta.pose_quaternion else 0, int(meta.collapse_mode), 0)
+
+
+def _check_points(pc, pose, trans, scale, focal, meta):
+    if pc.dim() != 3 or pc.shape[-1] != 3:
+        raise ValueError("point_cloud must be [B,N,3], got %s" % (tuple(pc.shape),))
+    B = pc.shape[0]
+    if meta.pose_quaternion:
+        if tuple(pose.shape) != (B, 4):
+            raise ValueError("Can't create a quaternion from a tensor with shape %s. "
+                             "The last dimension must be 4." % (tuple(pose.shape),))
+    else:
+        if tuple(pose.shape) != (B, 4, 4):
+            raise ValueError("camera matrix must be [B,4,4], got %s" % (tuple(pose.shape),))
+        if trans is not None:
+            raise ValueError("predicted_translation requires a quaternion pose "
+                             "(the reference's matrix branch cannot slice it)")
+    if trans is not None and tuple(trans.shape) != (B, 3):
+        raise ValueError("predicted_translation must be [B,3]")
+    for name, t in (("scaling_factor", scale), ("focal_length", focal)):
+        if t is not None and t.numel() != B:
+            raise ValueError("%s must have B=%d elements, got %s" % (name, B, tuple(t.shape)))
+
+
+def _taps_of(taps):
+    """taps: None or (tx, ty, tz) 1-D float32 tensors (any may be None)."""
+    if taps is None:
+        return (None, None, None), (0, 0, 0)
+    ts, ks = [], []
+    for t in taps:
+        if t is None:
+            ts.append(None)
+            ks.append(0)
+            continue
+        t = _c(t).reshape(-1)
+        k = t.numel()
+        if k % 2 != 1:
+            raise ValueError("even Gaussian kernel sizes are not supported (TF pads them asymmetrically)")
+        if k > _capi.DPC_MAX_TAPS:
+            raise ValueError("kernel size %d > %d" % (k, _capi.DPC_MAX_TAPS))
+        ts.append(t)
+        ks.append(k)
+    return tuple(ts), tuple(ks)
+
+
+class _Workspace(object):
+    """256-byte aligned scratch carved out of a torch allocation."""
+
+    def __init__(self, lib, shape, direction, like):
+        self.nbytes = lib.dpc_workspace_bytes(ctypes.byref(shape), direction)
+        self.buf = torch.empty((self.nbytes + 256 + 3) // 4, dtype=torch.float32, device=like.device)
+        base = self.buf.data_ptr()
+        self.ptr = ctypes.c_void_p((base + 255) & ~255)
+
+
+# ---------------------------------------------------------------------------
+# fused hot path
+# ---------------------------------------------------------------------------
+class ProjectFused(torch.autograd.Function):
+    """pointcloud_project_fast as ONE autograd node: (pc, pose, trans, scale,
+    focal) -> (proj [B,D,D,1], proj_depth [B,D,D,1] | None, tr_pc [B,N,3])."""
+
+    @staticmethod
+    def forward(ctx, pc, pose, trans, scale, focal, tx, ty, tz, meta):
+        _check_points(pc, pose, trans, scale, focal, meta)
+        lib = _lib_for(pc, pose, trans, scale, focal, tx, ty, tz)
+        pc, pose, trans, scale, focal = _c(pc), _c(pose), _c(trans), _c(scale), _c(focal)
+        (tx, ty, tz), K = _taps_of((tx, ty, tz))
+        B, N = pc.shape[0], pc.shape[1]
+        Dz, D = meta.Dz, meta.D
+        shape, params = _shape(B, N, meta, K), _params(meta)
+        new = lambda *s, **kw: torch.empty(*s, dtype=kw.get("dtype", torch.float32), device=pc.device)
+        tr_pc = new(B, N, 3)
+        grid_raw = new(B, Dz, D, D)
+        grid_blur = new(B, Dz, D, D)
+        drc = meta.collapse_mode == _capi.DPC_COLLAPSE_DRC
+        logt = new(B, D, D, dtype=torch.float64) if drc else None
+        proj = new(B, D, D, 1)
+        depth = new(B, D, D, 1) if drc else None
+        ws = _Workspace(lib, shape, 0, pc)
+        rc = lib.dpc_project_forward(_stream(lib, pc), ctypes.byref(shape), ctypes.byref(params),
+                                     _p(pc), _p(pose), _p(trans), _p(scale), _p(focal),
+                                     _p(tx), _p(ty), _p(tz), _p(tr_pc), _p(grid_raw), _p(grid_blur),
+                                     _p(logt), _p(proj), _p(depth), ws.ptr, ws.nbytes)
+        lib.check(rc, "dpc_project_forward")
+        ctx.meta, ctx.K = meta, K
+        ctx.has = (trans is not None, scale is not None, focal is not None)
+        ctx.scale_shape = None if scale is None else tuple(scale.shape)
+        ctx.focal_shape = None if focal is None else tuple(focal.shape)
+        ctx.save_for_backward(pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, grid_raw, grid_blur, logt)
+        return proj, depth, tr_pc
+
+    @staticmethod
+    def backward(ctx, dproj, ddepth, dtr):
+        pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, grid_raw, grid_blur, logt = ctx.saved_tensors
+        meta = ctx.meta
+        lib = _lib_for(pc)
+        B, N = pc.shape[0], pc.shape[1]
+        shape, params = _shape(B, N, meta, ctx.K), _params(meta)
+        dproj, ddepth, dtr = _c(dproj), _c(ddepth), _c(dtr)
+        if dproj is None and ddepth is None:
+            dproj = torch.zeros(B, meta.D, meta.D, 1, dtype=torch.float32, device=pc.device)
+        if meta.collapse_mode != _capi.DPC_COLLAPSE_DRC:
+            ddepth = None
+            if dproj is None:
+                dproj = torch.zeros(B, meta.D, meta.D, 1, dtype=torch.float32, device=pc.device)
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=pc.device)
+        dpc = new(B, N, 3)
+        dpose = torch.empty_like(pose)
+        dtrans = new(B, 3) if trans is not None else None
+        dscale = new(B) if scale is not None else None
+        dfocal = new(B) if focal is not None else None
+        ws = _Workspace(lib, shape, 1, pc)
+        rc = lib.dpc_project_backward(_stream(lib, pc), ctypes.byref(shape), ctypes.byref(params),
+                                      _p(pc), _p(pose), _p(trans), _p(scale), _p(focal),
+                                      _p(tx), _p(ty), _p(tz), _p(tr_pc), _p(grid_raw), _p(grid_blur),
+                                      _p(logt), _p(dproj), _p(ddepth), _p(dtr),
+                                      _p(dpc), _p(dpose), _p(dtrans), _p(dscale), _p(dfocal),
+                                      ws.ptr, ws.nbytes)
+        lib.check(rc, "dpc_project_backward")
+        if dscale is not None:
+            dscale = dscale.reshape(ctx.scale_shape)
+        if dfocal is not None:
+            dfocal = dfocal.reshape(ctx.focal_shape)
+        return dpc, dpose, dtrans, dscale, dfocal, None, None, None, None
+
+
+# ---------------------------------------------------------------------------
+# stage-level nodes (the reference's finer-grained API)
+# ---------------------------------------------------------------------------
+class Transform(torch.autograd.Function):
+    """pc_perspective_transform (dpc/util/point_cloud.py:157-216)."""
+
+    @staticmethod
+    def forward(ctx, pc, pose, trans, focal, meta):
+        _check_points(pc, pose, trans, None, focal, meta)
+        lib = _lib_for(pc, pose, trans, focal)
+        pc, pose, trans, focal = _c(pc), _c(pose), _c(trans), _c(focal)
+        B, N = pc.shape[0], pc.shape[1]
+        shape, params = _shape(B, N, meta), _params(meta)
+        tr_pc = torch.empty_like(pc)
+        rc = lib.dpc_transform_fwd(_stream(lib, pc), ctypes.byref(shape), ctypes.byref(params),
+                                   _p(pc), _p(pose), _p(trans), _p(focal), _p(tr_pc))
+        lib.check(rc, "dpc_transform_fwd")
+        ctx.meta = meta
+        ctx.focal_shape = None if focal is None else tuple(focal.shape)
+        ctx.save_for_backward(pc, pose, trans, focal)
+        return tr_pc
+
+    @staticmethod
+    def backward(ctx, dtr):
+        pc, pose, trans, focal = ctx.saved_tensors
+        lib = _lib_for(pc)
+        B, N = pc.shape[0], pc.shape[1]
+        shape, params = _shape(B, N, ctx.meta), _params(ctx.meta)
+        dtr = _c(dtr)
+        dpc = torch.empty_like(pc)
+        dpose = torch.empty_like(pose)
+        dtrans = torch.empty_like(trans) if trans is not None else None
+        dfocal = torch.empty(B, dtype=torch.float32, device=pc.device) if focal is not None else None
+        scratch = torch.empty(B * 16, dtype=torch.float32, device=pc.device)
+        rc = lib.dpc_transform_bwd(_stream(lib, pc), ctypes.byref(shape), ctypes.byref(params),
+                                   _p(pc), _p(pose), _p(trans), _p(focal), _p(dtr),
+                                   _p(dpc), _p(dpose), _p(dtrans), _p(dfocal), _p(scratch))
+        lib.check(rc, "dpc_transform_bwd")
+        if dfocal is not None:
+            dfocal = dfocal.reshape(ctx.focal_shape)
+        return dpc, dpose, dtrans, dfocal, None
+
+
+class Voxelize(torch.autograd.Function):
+    """pointcloud2voxels3d_fast (dpc/util/point_cloud.py:60-136): [B,N,3] -> [B,Dz,D,D]."""
+
+    @staticmethod
+    def forward(ctx, tr_pc, Dz, D):
+        if tr_pc.dim() != 3 or tr_pc.shape[-1] != 3:
+            raise ValueError("pc must be [B,N,3]")
+        lib = _lib_for(tr_pc)
+        tr_pc = _c(tr_pc)
+        B, N = tr_pc.shape[0], tr_pc.shape[1]
+        shape = DpcShape(B, N, int(Dz), int(D), 0, 0, 0)
+        grid = torch.empty(B, Dz, D, D, dtype=torch.float32, device=tr_pc.device)
+        rc = lib.dpc_voxelize_fwd(_stream(lib, tr_pc), ctypes.byref(shape), _p(tr_pc), _p(grid))
+        lib.check(rc, "dpc_voxelize_fwd")
+        ctx.dims = (Dz, D)
+        ctx.save_for_backward(tr_pc)
+        return grid
+
+    @staticmethod
+    def backward(ctx, dgrid):
+        (tr_pc,) = ctx.saved_tensors
+        lib = _lib_for(tr_pc)
+        Dz, D = ctx.dims
+        B, N = tr_pc.shape[0], tr_pc.shape[1]
+        shape = DpcShape(B, N, int(Dz), int(D), 0, 0, 0)
+        dgrid = _c(dgrid)
+        dtr = torch.empty_like(tr_pc)
+        rc = lib.dpc_voxelize_bwd(_stream(lib, tr_pc), ctypes.byref(shape), _p(tr_pc), _p(dgrid), _p(dtr))
+        lib.check(rc, "dpc_voxelize_bwd")
+        return dtr, None, None
+
+
+def _blur(lib, x, taps, K, order):
+    B, Dz, D = x.shape[0], x.shape[1], x.shape[2]
+    shape = DpcShape(B, 1, Dz, D, K[0], K[1], K[2])
+    out = torch.empty_like(x)
+    tmp = torch.empty_like(x)
+    rc = lib.dpc_blur3d(_stream(lib, x), ctypes.byref(shape), _p(x), _p(out), _p(taps[0]), _p(taps[1]),
+                        _p(taps[2]), _p(tmp), order)
+    lib.check(rc, "dpc_blur3d")
+    return out
+
+
+class Blur3d(torch.autograd.Function):
+    """smoothen_voxels3d, separable (dpc/util/point_cloud.py:139-145) on [B,Dz,D,D]."""
+
+    @staticmethod
+    def forward(ctx, vox, tx, ty, tz):
+        if vox.dim() != 4 or vox.shape[2] != vox.shape[3]:
+            raise ValueError("voxels must be [B,Dz,D,D]")
+        lib = _lib_for(vox, tx, ty, tz)
+        taps, K = _taps_of((tx, ty, tz))
+        ctx.K = K
+        ctx.save_for_backward(*[t for t in taps if t is not None])
+        ctx.present = [t is not None for t in taps]
+        return _blur(lib, _c(vox), taps, K, 0)
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved = list(ctx.saved_tensors)
+        taps = [saved.pop(0) if p else None for p in ctx.present]
+        dout = _c(dout)
+        lib = _lib_for(dout)
+        return _blur(lib, dout, taps, ctx.K, 1), None, None, None
+
+
+class DrcProjection(torch.autograd.Function):
+    """drc_projection (dpc/util/drc.py:47-123): [B,Dz,D,D] -> proj [B,D,D], probs [Dz+1,B,D,D]."""
+
+    @staticmethod
+    def forward(ctx, vox, meta, flip_h):
+        lib = _lib_for(vox)
+        vox = _c(vox)
+        B, Dz, D = vox.shape[0], vox.shape[1], vox.shape[2]
+        shape, params = DpcShape(B, 1, Dz, D, 0, 0, 0), _params(meta)
+        proj = torch.empty(B, D, D, dtype=torch.float32, device=vox.device)
+        probs = torch.empty(Dz + 1, B, D, D, dtype=torch.float32, device=vox.device)
+        rc = lib.dpc_drc_fwd(_stream(lib, vox), ctypes.byref(shape), ctypes.byref(params), _p(vox),
+                             _p(proj), _p(probs), int(flip_h))
+        lib.check(rc, "dpc_drc_fwd")
+        ctx.meta, ctx.flip = meta, int(flip_h)
+        ctx.save_for_backward(vox)
+        return proj, probs
+
+    @staticmethod
+    def backward(ctx, dproj, dprobs):
+        (vox,) = ctx.saved_tensors
+        lib = _lib_for(vox)
+        B, Dz, D = vox.shape[0], vox.shape[1], vox.shape[2]
+        shape, params = DpcShape(B, 1, Dz, D, 0, 0, 0), _params(ctx.meta)
+        dproj, dprobs = _c(dproj), _c(dprobs)
+        if dproj is None and dprobs is None:
+            return torch.zeros_like(vox), None, None
+        dvox = torch.empty_like(vox)
+        rc = lib.dpc_drc_bwd(_stream(lib, vox), ctypes.byref(shape), ctypes.byref(params), _p(vox),
+                             _p(dproj), _p(dprobs), _p(dvox), ctx.flip)
+        lib.check(rc, "dpc_drc_bwd")
+        return dvox, None, None
+
+
+class MaxCollapse(torch.autograd.Function):
+    """tf.reduce_max(voxels, [1]) (dpc/util/point_cloud.py:264-267)."""
+
+    @staticmethod
+    def forward(ctx, vox, flip_h):
+        lib = _lib_for(vox)
+        vox = _c(vox)
+        B, Dz, D = vox.shape[0], vox.shape[1], vox.shape[2]
+        shape = DpcShape(B, 1, Dz, D, 0, 0, 0)
+        proj = torch.empty(B, D, D, dtype=torch.float32, device=vox.device)
+        rc = lib.dpc_max_collapse_fwd(_stream(lib, vox), ctypes.byref(shape), _p(vox), _p(proj), int(flip_h))
+        lib.check(rc, "dpc_max_collapse_fwd")
+        ctx.flip = int(flip_h)
+        ctx.save_for_backward(vox)
+        return proj
+
+    @staticmethod
+    def backward(ctx, dproj):
+        (vox,) = ctx.saved_tensors
+        lib = _lib_for(vox)
+        B, Dz, D = vox.shape[0], vox.shape[1], vox.shape[2]
+        shape = DpcShape(B, 1, Dz, D, 0, 0, 0)
+        dvox = torch.empty_like(vox)
+        rc = lib.dpc_max_collapse_bwd(_stream(lib, vox), ctypes.byref(shape), _p(vox), _p(_c(dproj)),
+                                      _p(dvox), ctx.flip)
+        lib.check(rc, "dpc_max_collapse_bwd")
+        return dvox, None

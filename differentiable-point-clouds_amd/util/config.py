@@ -1,0 +1,54 @@
+"""Attribute-style config with the reference defaults that the hot path reads
+(dpc/resources/default_config.yaml).  The functions in
+this package accept ANY object with these attributes (e.g. the reference's
+EasyDict); this class is a convenience for callers that have none."""
+
+
+class Config(dict):
+    DEFAULTS = dict(
+        vox_size=64,                       # default_config.yaml:77
+        vox_size_z=-1,                     # :78
+        camera_distance=2.0,               # :81
+        focal_length=1.875,                # :79
+        pose_quaternion=True,              # :35
+        pc_gauss_kernel_size=11,           # :55 (experiments use 21)
+        pc_separable_gauss_filter=True,    # :56
+        pc_relative_sigma=1.0,             # :49
+        pc_relative_sigma_end=0.2,         # :50
+        max_number_of_steps=600000,        # :122
+        ptn_max_projection=False,          # :83
+        drc_logsum=True,                   # :88
+        drc_logsum_clip_val=1e-5,          # :89
+        drc_tf_cumulative=True,            # :90
+        max_depth=10.0,                    # :85
+        pc_rgb=False,                      # :61
+        pc_rgb_stop_points_gradient=False,
+        pc_rgb_clip_after_conv=False,
+        pc_rgb_divide_by_occupancies=False,
+        pc_rgb_divide_by_occupancies_epsilon=0.01,
+        # caller side (dpc/models/model_pc.py:225-299)
+        pc_fast=True, predict_pose=False, predict_translation=False,
+        pc_point_dropout=1.0, pc_learn_occupancy_scaling=True,
+        pose_predict_num_candidates=1, step_size=4, batch_size=8,
+        pc_num_points=8000, learn_focal_length=False,
+    )
+
+    def __init__(self, **kw):
+        super().__init__(self.DEFAULTS)
+        unknown = set(kw) - set(self.DEFAULTS)
+        if unknown:
+            raise KeyError("unknown config keys: %s" % sorted(unknown))  # config.py:7-41 is strict too
+        self.update(kw)
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def default_config(**kw):
+    return Config(**kw)

@@ -1,0 +1,74 @@
+"""Mirror of dpc/util/drc.py (differentiable ray consistency) over the HIP
+kernels.  Same names, argument order and tensor layouts as the reference:
+voxels [B,Dz,D,D,1] -> proj [B,D,D,1], event probabilities p [Dz+1,B,D,D,1].
+
+Only the reference's default configuration (log-space, tf.cumsum:
+drc_logsum=true, drc_tf_cumulative=true, default_config.yaml:88-90) is
+implemented; the non-log / python-loop variants raise NotImplementedError.
+"""
+import torch
+
+from .. import _capi, ops
+
+
+def _meta(cfg, Dz, D, collapse=_capi.DPC_COLLAPSE_DRC):
+    return ops.ProjMeta(Dz=int(Dz), D=int(D), camera_distance=float(cfg.camera_distance),
+                        focal_length=float(cfg.focal_length), eps=float(cfg.drc_logsum_clip_val),
+                        max_depth=float(cfg.max_depth),
+                        pose_quaternion=bool(getattr(cfg, "pose_quaternion", True)),
+                        collapse_mode=collapse)
+
+
+def _check_cfg(cfg):
+    if not getattr(cfg, "drc_logsum", True) or not getattr(cfg, "drc_tf_cumulative", True):
+        raise NotImplementedError("only the default log-space cumsum DRC (drc_logsum, drc_tf_cumulative)")
+
+
+def _grid4(voxels):
+    if voxels.dim() == 5:
+        if voxels.shape[-1] != 1:
+            raise ValueError("voxels must be [B,Dz,D,D,1]")
+        return voxels.reshape(voxels.shape[:4])
+    if voxels.dim() != 4:
+        raise ValueError("voxels must be [B,Dz,D,D,1]")
+    return voxels
+
+
+def drc_event_probabilities_impl(voxels, cfg, flip_h=False):
+    """dpc/util/drc.py:47-102.  Returns (p, proj) both with a trailing 1."""
+    _check_cfg(cfg)
+    v = _grid4(voxels)
+    proj, p = ops.DrcProjection.apply(v, _meta(cfg, v.shape[1], v.shape[2]), 1 if flip_h else 0)
+    return p.unsqueeze(-1), proj.unsqueeze(-1)
+
+
+def drc_event_probabilities(voxels, cfg):
+    return drc_event_probabilities_impl(voxels, cfg)[0]
+
+
+def drc_projection(voxels, cfg):
+    """dpc/util/drc.py:110-123 -> (proj [B,D,D,1], p [Dz+1,B,D,D,1])."""
+    p, proj = drc_event_probabilities_impl(voxels, cfg)
+    return proj, p
+
+
+def drc_depth_grid(cfg, z_size, device=None, dtype=torch.float32):
+    """dpc/util/drc.py:139-143: psi_i = i/Dz - 0.5 + camera_distance, psi_Dz = max_depth."""
+    zs = torch.as_tensor(float(z_size), dtype=dtype, device=device)
+    i_s = torch.arange(0, int(z_size), dtype=dtype, device=device)
+    di_s = i_s / zs - 0.5 + cfg.camera_distance
+    last = torch.full((1,), float(cfg.max_depth), dtype=dtype, device=device)
+    return torch.cat([di_s, last], dim=0)
+
+
+def drc_depth_projection(p, cfg):
+    """dpc/util/drc.py:146-153: sum_i p_i psi_i over [Dz+1,B,D,D,1].  (On the
+    fused path the depth image comes out of k_zfwd directly; this standalone
+    form is a single broadcast-multiply-reduce on the device.)"""
+    z_size = p.shape[0] - 1
+    psi = drc_depth_grid(cfg, z_size, device=p.device, dtype=p.dtype).reshape(-1, 1, 1, 1, 1)
+    return (p * psi).sum(dim=0)
+
+
+def project_volume_rgb_integral(cfg, p, rgb):
+    raise NotImplementedError("RGB integral is SURVEY.md 8(f) scope (pc_rgb is off by default)")

@@ -1,0 +1,52 @@
+"""Mirror of dpc/util/gauss_kernel.py:5-11,27-54 on torch tensors.
+
+The taps are a handful of floats recomputed whenever sigma changes (it is
+annealed with the global step, dpc/models/model_pc.py:35-40,146-153); they are
+produced with torch ops on whatever device is asked for and handed to the HIP
+blur kernels as device pointers."""
+import math
+
+import torch
+
+
+def _device(device):
+    if device is not None:
+        return torch.device(device)
+    return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+
+def gauss_kernel_1d(l, sig, device=None):
+    """Gaussian taps at integer offsets range(-l//2+1., l//2+1.), sum 1, fp32."""
+    l = int(l)
+    if l % 2 != 1:
+        raise ValueError("even kernel sizes are not supported: TF's SAME padding is "
+                         "asymmetric for them and the reference only uses odd sizes")
+    dev = sig.device if (isinstance(sig, torch.Tensor) and device is None) else _device(device)
+    xx = torch.arange(-l // 2 + 1.0, l // 2 + 1.0, dtype=torch.float32, device=dev)
+    sig = torch.as_tensor(sig, dtype=torch.float32, device=dev)
+    kernel = torch.exp(-xx ** 2 / (2.0 * sig ** 2))
+    return kernel / kernel.sum()
+
+
+def separable_kernels(kernel):
+    size = kernel.shape[0]
+    return [kernel.reshape(1, 1, size, 1, 1), kernel.reshape(1, size, 1, 1, 1),
+            kernel.reshape(size, 1, 1, 1, 1)]
+
+
+def smoothing_kernel(cfg, sigma, device=None):
+    """-> [k_x, k_y, k_z] with the reference's filter shapes [1,1,K,1,1],
+    [1,K,1,1,1], [Kz,1,1,1,1] (=> blur x first, z last)."""
+    fsz = cfg.pc_gauss_kernel_size
+    kernel_1d = gauss_kernel_1d(fsz, sigma, device)
+    if cfg.vox_size_z != -1:
+        ratio = cfg.vox_size_z / cfg.vox_size
+        fsz_z = int(math.floor(fsz * ratio))
+        if fsz_z % 2 == 0:
+            fsz_z += 1
+        kernel_1d_z = gauss_kernel_1d(fsz_z, sigma * ratio, device)
+        return [kernel_1d.reshape(1, 1, fsz, 1, 1), kernel_1d.reshape(1, fsz, 1, 1, 1),
+                kernel_1d_z.reshape(fsz_z, 1, 1, 1, 1)]
+    if not cfg.pc_separable_gauss_filter:
+        raise NotImplementedError("dense 3-D Gaussian kernel (pc_separable_gauss_filter=false)")
+    return separable_kernels(kernel_1d)

@@ -1,0 +1,172 @@
+"""Mirror of the reference's projector API (dpc/util/point_cloud.py) on
+PyTorch-ROCm tensors, executed by the hand-written HIP kernels.
+
+Same function names, argument order, tensor layouts and dict keys as the
+reference, so that a caller written against ``util.point_cloud`` (e.g.
+dpc/models/model_pc.py:241-244, dpc/run/predict.py:56-57,130-132) consumes it
+unchanged:
+
+    pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
+                            all_rgb, kernel=None, scaling_factor=None,
+                            focal_length=None) -> dict
+    pointcloud2voxels3d_fast(cfg, pc, rgb) -> (voxels [B,Dz,D,D], voxels_rgb)
+    smoothen_voxels3d(cfg, voxels [B,Dz,D,D,1], kernel) -> [B,Dz,D,D,1]
+    pc_perspective_transform(cfg, point_cloud, transform,
+                             predicted_translation=None, focal_length=None)
+
+TF1 graph mode never computes a tensor nobody fetches; eager PyTorch would.
+``pointcloud_project_fast`` therefore returns a dict whose cheap entries
+(``proj``, ``proj_depth``, ``tr_pc``) come from ONE fused autograd node and
+whose bulky entries (``voxels`` [B,Dz,D,D,1], ``drc_probs`` [Dz+1,B,D,D,1])
+are materialised on first access through the stage-level kernels, with
+autograd wired through ``tr_pc``.
+"""
+import torch
+
+from .. import _capi, ops
+from . import drc as _drc
+
+
+def _dims(cfg):
+    D = int(cfg.vox_size)
+    Dz = int(cfg.vox_size_z) if cfg.vox_size_z != -1 else D
+    return Dz, D
+
+
+def _meta(cfg, collapse=None):
+    Dz, D = _dims(cfg)
+    if collapse is None:
+        collapse = _capi.DPC_COLLAPSE_MAX if cfg.ptn_max_projection else _capi.DPC_COLLAPSE_DRC
+    return _drc._meta(cfg, Dz, D, collapse)
+
+
+def _flat_taps(cfg, kernel, device):
+    """Reference kernels are a list of 3 conv3d filters [1,1,K,1,1], [1,K,1,1,1],
+    [Kz,1,1,1,1] applied in list order; which axis each one blurs is read off
+    its shape (dpc/util/gauss_kernel.py:27-32)."""
+    if kernel is None:
+        return None, None, None
+    if not cfg.pc_separable_gauss_filter or isinstance(kernel, torch.Tensor):
+        raise NotImplementedError("dense 3-D Gaussian kernel (pc_separable_gauss_filter=false)")
+    taps = {"x": None, "y": None, "z": None}
+    for k in kernel:
+        k = torch.as_tensor(k, dtype=torch.float32)
+        if k.dim() != 5 or k.shape[3] != 1 or k.shape[4] != 1:
+            raise ValueError("separable kernel filters must be [kd,kh,kw,1,1], got %s" % (tuple(k.shape),))
+        kd, kh, kw = int(k.shape[0]), int(k.shape[1]), int(k.shape[2])
+        if sorted((kd, kh, kw))[:2] != [1, 1]:
+            raise ValueError("each separable filter must be 1-D, got %s" % (tuple(k.shape),))
+        axis = "z" if kd > 1 else ("y" if kh > 1 else "x")
+        if taps[axis] is not None:
+            raise NotImplementedError("two filters along the same axis")
+        taps[axis] = k.reshape(-1).to(device)
+    return taps["x"], taps["y"], taps["z"]
+
+
+def pc_perspective_transform(cfg, point_cloud, transform, predicted_translation=None, focal_length=None):
+    """dpc/util/point_cloud.py:157-216.  Returns [B,N,3] ordered (depth, y, x)."""
+    return ops.Transform.apply(point_cloud, transform, predicted_translation, focal_length, _meta(cfg))
+
+
+def pointcloud2voxels3d_fast(cfg, pc, rgb):
+    """dpc/util/point_cloud.py:60-136: trilinear scatter-add of [B,N,3] points
+    (already in the unit cube) into [B,Dz,D,D]."""
+    if rgb is not None:
+        raise NotImplementedError("RGB channels are SURVEY.md 8(f) scope (pc_rgb is off by default)")
+    Dz, D = _dims(cfg)
+    return ops.Voxelize.apply(pc, Dz, D), None
+
+
+def smoothen_voxels3d(cfg, voxels, kernel):
+    """dpc/util/point_cloud.py:139-145 on [B,Dz,D,D,1]."""
+    tx, ty, tz = _flat_taps(cfg, kernel, voxels.device)
+    v = _drc._grid4(voxels)
+    out = ops.Blur3d.apply(v, tx, ty, tz)
+    return out.unsqueeze(-1) if voxels.dim() == 5 else out
+
+
+def convolve_rgb(cfg, voxels_rgb, kernel):
+    raise NotImplementedError("RGB channels are SURVEY.md 8(f) scope")
+
+
+def pointcloud2voxels(cfg, input_pc, sigma):
+    raise NotImplementedError("exact O(N D^3) Gaussian voxeliser (pc_fast=false) is SURVEY.md 8(f) scope")
+
+
+def pointcloud_project(cfg, point_cloud, transform, sigma):
+    raise NotImplementedError("slow path (pc_fast=false) is SURVEY.md 8(f) scope")
+
+
+class ProjectionOutputs(dict):
+    """The reference's output dict.  ``voxels`` and ``drc_probs`` are computed
+    on first access (TF1 graph pruning semantics, see module docstring)."""
+
+    _LAZY = ("voxels", "drc_probs")
+
+    def __init__(self, eager, make_voxels, make_probs):
+        super().__init__(eager)
+        self._makers = {"voxels": make_voxels, "drc_probs": make_probs}
+        for k in self._LAZY:
+            dict.__setitem__(self, k, None)
+
+    def _materialise(self, k):
+        mk = self._makers.get(k)
+        if mk is not None:
+            self._makers[k] = None
+            dict.__setitem__(self, k, mk())
+
+    def __getitem__(self, k):
+        if k in self._LAZY:
+            self._materialise(k)
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        for k in self._LAZY:
+            self._materialise(k)
+        return dict.items(self)
+
+    def values(self):
+        for k in self._LAZY:
+            self._materialise(k)
+        return dict.values(self)
+
+
+def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
+                            all_rgb, kernel=None, scaling_factor=None, focal_length=None):
+    """dpc/util/point_cloud.py:229-290."""
+    if all_rgb is not None:
+        raise NotImplementedError("RGB channels are SURVEY.md 8(f) scope (pc_rgb is off by default)")
+    _drc._check_cfg(cfg)
+    meta = _meta(cfg)
+    tx, ty, tz = _flat_taps(cfg, kernel, point_cloud.device)
+    proj, proj_depth, tr_pc = ops.ProjectFused.apply(point_cloud, transform, predicted_translation,
+                                                     scaling_factor, focal_length, tx, ty, tz, meta)
+    state = {}
+
+    def make_voxels():
+        if "voxels" not in state:
+            v, _ = pointcloud2voxels3d_fast(cfg, tr_pc, None)
+            v = torch.clamp(v, 0.0, 1.0)
+            if kernel is not None:
+                v = ops.Blur3d.apply(v, tx, ty, tz)
+            if scaling_factor is not None:
+                v = torch.clamp(v * scaling_factor.reshape(-1, 1, 1, 1), 0.0, 1.0)
+            state["voxels"] = v.unsqueeze(-1)
+        return state["voxels"]
+
+    def make_probs():
+        if cfg.ptn_max_projection:
+            return None
+        v = make_voxels()
+        p, _ = _drc.drc_event_probabilities_impl(v, cfg, flip_h=True)   # tf.reverse(drc_probs, [2])
+        return p
+
+    eager = {"proj": proj, "tr_pc": tr_pc, "voxels_rgb": None, "proj_rgb": None, "proj_depth": proj_depth}
+    return ProjectionOutputs(eager, make_voxels, make_probs)
+
+
+def pc_point_dropout(points, rgb, keep_prob):
+    raise NotImplementedError("device-side point dropout is SURVEY.md 8(f) scope")

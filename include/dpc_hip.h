@@ -1,0 +1,149 @@
+/* dpc_hip.h -- C ABI of the MI355X (gfx950) differentiable point-cloud projector.
+ *
+ * The reference (eldar/differentiable-point-clouds) has NO native / FFI
+ * boundary: its hot path sits behind plain Python functions built from stock
+ * TensorFlow ops.  Each entry point below cites the reference function
+ * (file:line under /root/reference) whose arithmetic it replaces; the Python
+ * functions with the reference's own names and signatures that sit on top of
+ * this ABI live in differentiable-point-clouds_amd/util/ (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to contiguous fp32 (unless noted);
+ *     inputs are never written; outputs are fully overwritten
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t); no sync, no
+ *     allocation, no global state; safe from several threads on different
+ *     streams / devices
+ *   - return value: 0 = ok, <0 = invalid argument (DPC_E_*), >0 = hipError_t
+ *   - grids are [B, Dz, D, D] (z = depth axis = component 0 of the transformed
+ *     cloud, then y, then x; x fastest); images are [B, D, D] (the trailing
+ *     channel dim of the reference layouts has size 1 and is implicit);
+ *     `flip_h` applies the reference's tf.reverse along H
+ *     (dpc/util/point_cloud.py:270,273): image row h <-> grid row D-1-h
+ *   - nullable pointers are marked; a null `taps_*` with K*=0 means "no blur"
+ */
+#ifndef DPC_HIP_H
+#define DPC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dpc_stream_t; /* hipStream_t */
+
+#define DPC_OK 0
+#define DPC_E_NULL (-1)      /* required pointer is null          */
+#define DPC_E_SHAPE (-2)     /* non-positive / unsupported sizes  */
+#define DPC_E_TAPS (-3)      /* even or too large kernel size     */
+#define DPC_E_WORKSPACE (-4) /* workspace too small / misaligned  */
+#define DPC_E_MODE (-5)      /* unsupported parameter combination */
+
+#define DPC_MAX_TAPS 63
+
+#define DPC_COLLAPSE_DRC 0 /* dpc/util/drc.py:47-123            */
+#define DPC_COLLAPSE_MAX 1 /* dpc/util/point_cloud.py:264-267    */
+
+typedef struct DpcShape {
+  int32_t B;          /* instances (model x view x pose candidate) */
+  int32_t N;          /* points per instance                       */
+  int32_t Dz;         /* grid depth  (cfg.vox_size_z or vox_size)  */
+  int32_t D;          /* grid height = width (cfg.vox_size)        */
+  int32_t Kx, Ky, Kz; /* odd tap counts, 0 = axis not blurred      */
+} DpcShape;
+
+typedef struct DpcParams {
+  float camera_distance;      /* cfg.camera_distance      (2.0)    */
+  float focal_length;         /* cfg.focal_length         (1.875)  */
+  float eps;                  /* cfg.drc_logsum_clip_val  (1e-5)   */
+  float max_depth;            /* cfg.max_depth            (10.0)   */
+  int32_t pose_is_quaternion; /* 1: pose [B,4] (w,x,y,z); 0: [B,4,4] */
+  int32_t collapse_mode;      /* DPC_COLLAPSE_*                    */
+  int32_t flags;              /* reserved, 0                       */
+} DpcParams;
+
+const char* dpc_version(void);
+
+/* Bytes of scratch `dpc_project_forward` (direction 0) / `dpc_project_backward`
+ * (direction 1) need.  256-byte aligned device memory. */
+size_t dpc_workspace_bytes(const DpcShape* shape, int direction);
+
+/* ---- fused hot path ------------------------------------------------------
+ * pointcloud_project_fast, dpc/util/point_cloud.py:229-290, i.e.
+ *   pc_perspective_transform (:157-216, quaternion.py:96-117)
+ *   -> pointcloud2voxels3d_fast (:60-136) -> clip (:240)
+ *   -> smoothen_voxels3d (:139-145) -> scale*clip (:249-253)
+ *   -> drc_projection / reduce_max (drc.py:110-123 / :264-267)
+ *   -> drc_depth_projection (drc.py:146-153) -> flips (:270,273).
+ * Saved for backward (caller-owned): tr_pc [B,N,3], grid_raw [B,Dz,D,D]
+ * (pre-clip scatter), grid_blur [B,Dz,D,D] (post-blur, pre-scale),
+ * ray_logt [B,D,D] float64 (total log-transmittance per ray, grid-row order).
+ * trans/scale/focal/taps/proj_depth nullable.  proj, proj_depth are H-flipped. */
+int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params,
+                        const float* pc, const float* pose, const float* trans /*[B,3]|null*/,
+                        const float* scale /*[B]|null*/, const float* focal /*[B]|null*/,
+                        const float* taps_x, const float* taps_y, const float* taps_z,
+                        float* tr_pc, float* grid_raw, float* grid_blur, double* ray_logt,
+                        float* proj, float* proj_depth /*null for MAX*/,
+                        void* workspace, size_t workspace_bytes);
+
+/* Backward of the above = what TF autodiff builds for
+ * dpc/run/train.py:92 over the ops of point_cloud.py:229-290.
+ * Upstream: dproj [B,D,D] (H-flipped layout), dproj_depth [B,D,D]|null,
+ * dtr_pc_in [B,N,3]|null (gradient arriving through the `tr_pc` output).
+ * Outputs: dpc [B,N,3], dpose [B,4]|[B,4,4], dtrans [B,3]|null, dscale [B]|null,
+ * dfocal [B]|null (non-null only if the matching input was given). */
+int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params,
+                         const float* pc, const float* pose, const float* trans,
+                         const float* scale, const float* focal,
+                         const float* taps_x, const float* taps_y, const float* taps_z,
+                         const float* tr_pc, const float* grid_raw, const float* grid_blur,
+                         const double* ray_logt,
+                         const float* dproj, const float* dproj_depth, const float* dtr_pc_in,
+                         float* dpc, float* dpose, float* dtrans, float* dscale, float* dfocal,
+                         void* workspace, size_t workspace_bytes);
+
+/* ---- stage-level entry points (finer-grained reference API) --------------- */
+
+/* pc_perspective_transform, dpc/util/point_cloud.py:157-216 */
+int dpc_transform_fwd(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params,
+                      const float* pc, const float* pose, const float* trans, const float* focal,
+                      float* tr_pc);
+/* scratch: >= B*16 floats (zeroed by the call) */
+int dpc_transform_bwd(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params,
+                      const float* pc, const float* pose, const float* trans, const float* focal,
+                      const float* dtr_pc, float* dpc, float* dpose, float* dtrans, float* dfocal,
+                      float* scratch);
+
+/* pointcloud2voxels3d_fast, dpc/util/point_cloud.py:60-136 (zero-fills, then
+ * trilinear scatter-add; out-of-cube / NaN points dropped) and its gather VJP */
+int dpc_voxelize_fwd(dpc_stream_t stream, const DpcShape* shape, const float* tr_pc, float* grid);
+int dpc_voxelize_bwd(dpc_stream_t stream, const DpcShape* shape, const float* tr_pc,
+                     const float* dgrid, float* dtr_pc);
+
+/* smoothen_voxels3d (separable), dpc/util/point_cloud.py:139-145.  order 0 =
+ * x,y,z (gauss_kernel.py:27-32); order 1 = adjoint (z first).  The blur is
+ * self-adjoint for odd symmetric taps.  tmp: one grid [B,Dz,D,D]; in != out. */
+int dpc_blur3d(dpc_stream_t stream, const DpcShape* shape, const float* in, float* out,
+               const float* taps_x, const float* taps_y, const float* taps_z, float* tmp, int order);
+
+/* drc_projection, dpc/util/drc.py:47-123: voxels [B,Dz,D,D] -> proj [B,D,D],
+ * probs [Dz+1,B,D,D] (nullable).  flip_h applies to both outputs. */
+int dpc_drc_fwd(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params,
+                const float* voxels, float* proj, float* probs, int flip_h);
+int dpc_drc_bwd(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params,
+                const float* voxels, const float* dproj /*nullable*/, const float* dprobs /*nullable*/,
+                float* dvoxels, int flip_h);
+
+/* tf.reduce_max(voxels, [1]), dpc/util/point_cloud.py:264-267; ties share the
+ * gradient equally (TF _MinOrMaxGrad). */
+int dpc_max_collapse_fwd(dpc_stream_t stream, const DpcShape* shape, const float* voxels,
+                         float* proj, int flip_h);
+int dpc_max_collapse_bwd(dpc_stream_t stream, const DpcShape* shape, const float* voxels,
+                         const float* dproj, float* dvoxels, int flip_h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPC_HIP_H */

@@ -25,3 +25,22 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def emu_library():
+    """CPU emulation build of the kernel source (tests/hipemu): same .hip file,
+    compiled with g++ against a thread-per-lane HIP model.  Test-only."""
+    import subprocess
+    emu_dir = os.path.join(ROOT, "tests", "hipemu")
+    subprocess.check_call(["make", "-s", "-C", emu_dir])
+    import dpc_amd
+    return dpc_amd._capi.DpcLibrary(os.path.join(emu_dir, "libdpc_emu.so"), host_memory=True)
+
+
+@pytest.fixture()
+def emu(emu_library):
+    import dpc_amd
+    prev = dpc_amd._capi.set_library(emu_library)
+    yield emu_library
+    dpc_amd._capi.set_library(prev)
