@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Headline benchmark: projected views/sec, forward + backward, of
+pointcloud_project_fast on synthetic point clouds (BASELINE.json configs[1]:
+8000 pts -> 128^3 -> 128^2, batch 32 per GPU, sigma 1.6, K = 11).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one fwd+bwd pass of the projector over one batch of B views per
+GPU (grads w.r.t. point_cloud, transform, scaling_factor given
+dproj = (proj - gt)/B, the reference's L2 loss gradient, model_pc.py:414-415).
+The path shards over instances with no data-path collective (weak scaling,
+B views per GPU); ranks only meet at the timing barriers.
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline     dominant kernel: algorithmic bytes per launch / its mean launch
+               duration (HIP events on the launch stream, dpc_profile_*),
+               against the 8 TB/s HBM3E peak; plus step_* = the whole fwd+bwd
+               step against SURVEY.md 8(d)'s 8 V + P bytes per view
+  cpu_baseline the oracle's op-for-op torch-CPU restatement of the reference
+               graph (oracle/reference_cpu.py, kind "port"), timed on a bounded
+               sample on this host's cores (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import dpc_amd  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def build_case(cfg_id, B, device, seed_offset=0):
+    c = dpc_amd.synthetic.config_inputs(cfg_id, B=B, seed_offset=seed_offset)
+    cfg = dpc_amd.default_config(vox_size=c["D"], pc_gauss_kernel_size=c["K"])
+    t = lambda a: torch.tensor(a, device=device, requires_grad=True)
+    case = dict(cfg=cfg, pc=t(c["pc"]), pose=t(c["pose"]), scale=t(c["scale"]),
+                kern=dpc_amd.smoothing_kernel(cfg, c["sigma"], device=device),
+                gt=torch.tensor(dpc_amd.synthetic.disk_gt(c["B"], c["D"]), device=device),
+                B=c["B"], N=c["N"], D=c["D"], K=c["K"], sigma=c["sigma"])
+    return case
+
+
+def step(case):
+    out = dpc_amd.pointcloud_project_fast(case["cfg"], case["pc"], case["pose"], None, None, case["kern"],
+                                          scaling_factor=case["scale"])
+    proj = out["proj"]
+    dproj = (proj.detach() - case["gt"]) / case["B"]
+    return torch.autograd.grad(proj, [case["pc"], case["pose"], case["scale"]], dproj)
+
+
+def kernel_algorithmic_bytes(label, case):
+    """Compulsory HBM bytes of ONE launch over the batch (DESIGN.md 'Kernels'):
+    every dense kernel reads one grid and writes one grid (2 V per view); the
+    zero-fill writes one (1 V); point kernels move O(N) bytes + their atomics."""
+    V = 4 * case["D"] ** 3
+    B, N = case["B"], case["N"]
+    dense = {"zfwd": 2 * V, "zbwd": 2 * V, "blur_plane": 2 * V, "blur_z": 2 * V, "memset_grid": V}
+    if label in dense:
+        return B * dense[label]
+    if label == "points_fwd":
+        return B * (N * 24 + 8 * N * 8)
+    if label == "points_bwd":
+        return B * (N * 36 + 8 * N * 8)
+    return 0
+
+
+def cpu_baseline(cfg_id, seconds_budget=20.0):
+    """oracle/reference_cpu.py on a bounded sample of the same workload."""
+    from oracle import reference_cpu as rcpu
+    c = dpc_amd.synthetic.config_inputs(cfg_id, B=2)
+    cfg = rcpu.Cfg(vox_size=c["D"], pc_gauss_kernel_size=c["K"])
+    kern = rcpu.smoothing_kernel(cfg, c["sigma"])
+    gt = torch.tensor(dpc_amd.synthetic.disk_gt(2, c["D"]))
+    pc = torch.tensor(c["pc"], requires_grad=True)
+    pose = torch.tensor(c["pose"], requires_grad=True)
+    scale = torch.tensor(c["scale"], requires_grad=True)
+
+    def one():
+        out = rcpu.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale)
+        dproj = (out["proj"].detach() - gt) / 2
+        torch.autograd.grad(out["proj"], [pc, pose, scale], dproj)
+
+    one()                                   # warm-up (allocator, threads)
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_start < seconds_budget and len(times) < 12):
+        t0 = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": 2.0 / med, "unit": "views/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "B=2 of the %d-view batch (same N=%d, %d^3, K=%d), fwd+bwd, median of %d runs, "
+                      "oracle/reference_cpu.py (torch-CPU op-for-op restatement of the TF1 graph)"
+                      % (dpc_amd.synthetic.CONFIGS[cfg_id]["B"], c["N"], c["D"], c["K"], len(times)),
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 5])
+    ap.add_argument("--batch", type=int, default=None, help="views per GPU (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the projector has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    lib = dpc_amd.get_library()
+    case = build_case(args.config, args.batch, device, seed_offset=1000 * rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(case)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(case)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel durations (HIP events on the launch stream), rank 0 ----------
+    roof = None
+    if rank == 0:
+        psteps = max(3, min(args.steps, 20))
+        lib.profile(True)
+        for _ in range(psteps):
+            step(case)
+        torch.cuda.synchronize()
+        recs = lib.profile_records()
+        lib.profile(False)
+        agg = {}
+        for label, ms in recs:
+            a = agg.setdefault(label, [0, 0.0])
+            a[0] += 1
+            a[1] += ms
+        per_step = {k: v[1] / psteps for k, v in agg.items()}
+        dom = max(agg, key=lambda k: agg[k][1])
+        dom_ms = agg[dom][1] / agg[dom][0]
+        alg = kernel_algorithmic_bytes(dom, case)
+        traffic, tsrc = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                ent = tj.get("config%d" % args.config, {}).get(dom)
+                if ent is not None and case["B"] == tj.get("config%d" % args.config, {}).get("B"):
+                    traffic, tsrc = ent, "profiles/traffic.json (rocprofv3 --pmc passes, see profiles/README.md)"
+            except (ValueError, OSError):
+                pass
+        step_bytes = dpc_amd.synthetic.algorithmic_bytes_per_view(case["N"], case["D"], case["D"]) * case["B"]
+        ms_step = elapsed / args.steps * 1e3
+        roof = {"bound": "hbm", "kernel": dom, "achieved": alg / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": alg / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": tsrc, "kernel_ms": dom_ms, "kernel_alg_bytes": alg,
+                "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items())},
+                "step_alg_bytes": step_bytes, "step_achieved": step_bytes / (ms_step * 1e-3) / 1e9,
+                "step_frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    if rank == 0:
+        views = world * case["B"] * args.steps
+        line = {
+            "metric": "projected views/sec (fwd+bwd), %d pts->%d^3->%d^2 at bs=%d per GPU"
+                      % (case["N"], case["D"], case["D"], case["B"]),
+            "value": views / elapsed, "unit": "views/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[%d]: pointcloud_project_fast fwd+bwd, N=%d, "
+                                   "grid %d^3, K=%d, sigma=%.1f, batch %d views per GPU, shell point clouds, "
+                                   "dproj=(proj-gt)/B" % ({1: 0, 2: 1, 5: 4}[args.config], case["N"], case["D"],
+                                                         case["K"], case["sigma"], case["B"]),
+                       "global_batch": world * case["B"], "K": case["K"], "parallelism": "views sharded x%d, "
+                       "no data-path collective" % world},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -47,6 +47,11 @@ _PP = ctypes.POINTER(DpcParams)
 SIGNATURES = {
     "dpc_version": (ctypes.c_char_p, []),
     "dpc_workspace_bytes": (ctypes.c_size_t, [_SP, ctypes.c_int]),
+    "dpc_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "dpc_profile_count": (ctypes.c_int, []),
+    "dpc_profile_get": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
+                                       ctypes.POINTER(ctypes.c_float)]),
+    "dpc_debug_copy": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, ctypes.c_int]),
     "dpc_project_forward": (ctypes.c_int, [_P, _SP, _PP] + [_P] * 8 + [_P] * 6 + [_P, ctypes.c_size_t]),
     "dpc_project_backward": (ctypes.c_int, [_P, _SP, _PP] + [_P] * 8 + [_P] * 4 + [_P] * 3 + [_P] * 5
                              + [_P, ctypes.c_size_t]),
@@ -84,6 +89,18 @@ class DpcLibrary(object):
 
     def version(self):
         return self.dpc_version().decode()
+
+    def profile(self, on):
+        self.check(self.dpc_profile_enable(1 if on else 0), "dpc_profile_enable")
+
+    def profile_records(self):
+        """[(label, milliseconds)] of every launch since profile(True); syncs."""
+        out = []
+        for i in range(self.dpc_profile_count()):
+            name, ms = ctypes.c_char_p(), ctypes.c_float()
+            self.check(self.dpc_profile_get(i, ctypes.byref(name), ctypes.byref(ms)), "dpc_profile_get")
+            out.append((name.value.decode(), float(ms.value)))
+        return out
 
     @staticmethod
     def check(rc, what):

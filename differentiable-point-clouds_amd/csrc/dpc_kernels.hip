@@ -37,7 +37,7 @@
 #include "hip_emu.h"
 #else
 #include <hip/hip_runtime.h>
-#define DPC_LAUNCH(kernel, grid, block, smem, stream, ...) \
+#define DPC_LAUNCH_RAW(kernel, grid, block, smem, stream, ...) \
   hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__)
 #define DPC_DYN_SMEM(type, name)                                             \
   extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; \
@@ -45,6 +45,72 @@
 #endif
 
 #include <math.h>
+
+#include <mutex>
+#include <vector>
+
+// ---------------------------------------------------------------------------
+// optional per-kernel timing: HIP events recorded on the launch stream around
+// every launch while enabled (bench.py's roofline leg).  Off by default; not
+// meant for concurrent use from several threads.
+// ---------------------------------------------------------------------------
+namespace dpcprof {
+struct Rec {
+  const char* label;
+#ifndef DPC_EMU
+  hipEvent_t a, b;
+#endif
+};
+static std::mutex g_mu;
+static bool g_on = false;
+static std::vector<Rec> g_recs;
+static inline bool begin(const char* label, hipStream_t st) {
+  if (!g_on) return false;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Rec r;
+  r.label = label;
+#ifndef DPC_EMU
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return false;
+  (void)hipEventRecord(r.a, st);
+#else
+  (void)st;
+#endif
+  g_recs.push_back(r);
+  return true;
+}
+static inline void end(hipStream_t st) {
+#ifndef DPC_EMU
+  std::lock_guard<std::mutex> lk(g_mu);
+  (void)hipEventRecord(g_recs.back().b, st);
+#else
+  (void)st;
+#endif
+}
+static inline void clear() {
+  std::lock_guard<std::mutex> lk(g_mu);
+#ifndef DPC_EMU
+  for (auto& r : g_recs) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+#endif
+  g_recs.clear();
+}
+}  // namespace dpcprof
+
+#define DPC_LAUNCH(label, kernel, grid, block, smem, stream, ...)          \
+  do {                                                                     \
+    const bool prof_ = dpcprof::begin(label, stream);                      \
+    DPC_LAUNCH_RAW(kernel, grid, block, smem, stream, __VA_ARGS__);        \
+    if (prof_) dpcprof::end(stream);                                       \
+  } while (0)
+
+static inline hipError_t dpc_memset(const char* label, void* p, size_t n, hipStream_t st) {
+  const bool prof_ = dpcprof::begin(label, st);
+  hipError_t e = hipMemsetAsync(p, 0, n, st);
+  if (prof_) dpcprof::end(st);
+  return e;
+}
 
 #define DPC_BLOCK 256
 #define DPC_XC 8  // x-blur outputs per thread (register window)
@@ -938,6 +1004,19 @@ k_max_bwd(const float* __restrict__ vox, const float* __restrict__ scale,
   }
 }
 
+// streaming copy with W floats per lane: known byte counts for calibrating the
+// rocprofv3 FETCH_SIZE / WRITE_SIZE counters on gfx950 (MI355X_MICROARCH.md HBM)
+template <int W>
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_copy(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x * W;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * W; i + W <= n; i += stride) {
+    float v[W];
+    load_cx<W>(src + i, v);
+    store_cx<W>(dst + i, v);
+  }
+}
+
 // ===========================================================================
 // host side: validation, launch geometry, C ABI
 // ===========================================================================
@@ -991,7 +1070,7 @@ int launch_blur_plane(hipStream_t st, const DpcShape& S, const float* in, float*
   const bool fixed_ok = (Kx == 0 || Ky == 0 || Kx == Ky);
   const int K = Kx > 0 ? Kx : Ky;
 #define DPC_PLANE_CASE(KC)                                                                          \
-  DPC_LAUNCH((k_blur_plane<KC>), grid, block, bytes, st, in, out, tx, ty, Kx, Ky, S.Dz, D, TY, nyt, \
+  DPC_LAUNCH("blur_plane", (k_blur_plane<KC>), grid, block, bytes, st, in, out, tx, ty, Kx, Ky, S.Dz, D, TY, nyt, \
              PA, PB, clip_in, (int)nblocks)
   if (fixed_ok && K == 5) {
     DPC_PLANE_CASE(5);
@@ -1044,11 +1123,11 @@ int launch_blur_z(hipStream_t st, const DpcShape& S, const float* in, float* out
   if (z_fixed(Kz) && Kz > 0) {
     const int cx = pick_cx(S.D);
     const dim3 grid = col_grid(S, cx);
-#define DPC_M(KC, CXV) DPC_LAUNCH((k_blur_z<KC, CXV>), grid, block, 0, st, in, out, tz, S.Dz, S.D)
+#define DPC_M(KC, CXV) DPC_LAUNCH("blur_z", (k_blur_z<KC, CXV>), grid, block, 0, st, in, out, tz, S.Dz, S.D)
     DPC_Z_DISPATCH(Kz, cx, DPC_M);
 #undef DPC_M
   } else {
-    DPC_LAUNCH((k_blur_z_generic), col_grid(S, 1), block, 0, st, in, out, tz, Kz, S.Dz, S.D);
+    DPC_LAUNCH("blur_z_generic", (k_blur_z_generic), col_grid(S, 1), block, 0, st, in, out, tz, Kz, S.Dz, S.D);
   }
   return last_error();
 }
@@ -1061,7 +1140,7 @@ int launch_zfwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const flo
   const int cx = pick_cx(S.D);
   const dim3 grid = col_grid(S, cx);
 #define DPC_M(KC, CXV)                                                                                \
-  DPC_LAUNCH((k_zfwd<KC, CXV>), grid, block, 0, st, P, in, (Kz > 0 ? tz : (const float*)nullptr), scale, \
+  DPC_LAUNCH("zfwd", (k_zfwd<KC, CXV>), grid, block, 0, st, P, in, (Kz > 0 ? tz : (const float*)nullptr), scale, \
              g2_out, probs, proj, depth, logt, S.B, S.Dz, S.D, clip_in, flip_h)
   DPC_Z_DISPATCH(Kz, cx, DPC_M);
 #undef DPC_M
@@ -1075,7 +1154,7 @@ int launch_zbwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const flo
   const int cx = pick_cx(S.D);
   const dim3 grid = col_grid(S, cx);
 #define DPC_M(KC, CXV)                                                                                \
-  DPC_LAUNCH((k_zbwd<KC, CXV>), grid, block, 0, st, P, g2, (Kz > 0 ? tz : (const float*)nullptr), scale, \
+  DPC_LAUNCH("zbwd", (k_zbwd<KC, CXV>), grid, block, 0, st, P, g2, (Kz > 0 ? tz : (const float*)nullptr), scale, \
              logt, dproj, ddepth, dprobs, dgz, dscale, S.B, S.Dz, S.D, flip_h)
   DPC_Z_DISPATCH(Kz, cx, DPC_M);
 #undef DPC_M
@@ -1086,12 +1165,12 @@ int launch_points_bwd(hipStream_t st, const DpcShape& S, const DpcParams& P, con
                       const float* pose, const float* trans, const float* focal, const float* tr_pc,
                       const float* dgrid, const float* mask, const float* taps_x, const float* dtr_in,
                       bool gather, float* dpc, float* dpose, float* dtrans, float* dfocal, float* accum) {
-  hipError_t e = hipMemsetAsync(accum, 0, sizeof(float) * 16 * (size_t)S.B, st);
+  hipError_t e = dpc_memset("memset_small", accum, sizeof(float) * 16 * (size_t)S.B, st);
   if (e != hipSuccess) return (int)e;
   const dim3 grid = point_grid(S), block(DPC_BLOCK, 1, 1);
   const bool quat = P.pose_is_quaternion != 0;
 #define DPC_PB(Q, G)                                                                                  \
-  DPC_LAUNCH((k_points_bwd<Q, G>), grid, block, 0, st, S, P, pc, pose, trans, focal, tr_pc, dgrid, mask, \
+  DPC_LAUNCH("points_bwd", (k_points_bwd<Q, G>), grid, block, 0, st, S, P, pc, pose, trans, focal, tr_pc, dgrid, mask, \
              taps_x, dtr_in, dpc, accum)
   if (quat && gather) DPC_PB(true, true);
   else if (quat) DPC_PB(true, false);
@@ -1100,9 +1179,9 @@ int launch_points_bwd(hipStream_t st, const DpcShape& S, const DpcParams& P, con
 #undef DPC_PB
   const dim3 fg((S.B + 63) / 64, 1, 1), fb(64, 1, 1);
   if (quat)
-    DPC_LAUNCH((k_pose_finalize<true>), fg, fb, 0, st, S, P, pose, accum, dpose, dtrans, dfocal);
+    DPC_LAUNCH("pose_finalize", (k_pose_finalize<true>), fg, fb, 0, st, S, P, pose, accum, dpose, dtrans, dfocal);
   else
-    DPC_LAUNCH((k_pose_finalize<false>), fg, fb, 0, st, S, P, pose, accum, dpose, dtrans, dfocal);
+    DPC_LAUNCH("pose_finalize", (k_pose_finalize<false>), fg, fb, 0, st, S, P, pose, accum, dpose, dtrans, dfocal);
   return last_error();
 }
 
@@ -1111,6 +1190,49 @@ int launch_points_bwd(hipStream_t st, const DpcShape& S, const DpcParams& P, con
 extern "C" {
 
 const char* dpc_version(void) { return "dpc_hip 0.1.0 (gfx950)"; }
+
+int dpc_profile_enable(int on) {
+  dpcprof::clear();
+  std::lock_guard<std::mutex> lk(dpcprof::g_mu);
+  dpcprof::g_on = on != 0;
+  return DPC_OK;
+}
+
+int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, int width) {
+  if (!src || !dst) return DPC_E_NULL;
+  if (n == 0 || (n % 4) != 0) return DPC_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(256 * 8, 1, 1), block(DPC_BLOCK, 1, 1);
+  if (width == 4)
+    DPC_LAUNCH("copy4", (k_copy<4>), grid, block, 0, st, src, dst, n);
+  else if (width == 2)
+    DPC_LAUNCH("copy2", (k_copy<2>), grid, block, 0, st, src, dst, n);
+  else if (width == 1)
+    DPC_LAUNCH("copy1", (k_copy<1>), grid, block, 0, st, src, dst, n);
+  else
+    return DPC_E_MODE;
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? DPC_OK : (int)e;
+}
+
+int dpc_profile_count(void) {
+  std::lock_guard<std::mutex> lk(dpcprof::g_mu);
+  return (int)dpcprof::g_recs.size();
+}
+
+int dpc_profile_get(int i, const char** label, float* ms) {
+  std::lock_guard<std::mutex> lk(dpcprof::g_mu);
+  if (i < 0 || i >= (int)dpcprof::g_recs.size() || !label || !ms) return DPC_E_NULL;
+  *label = dpcprof::g_recs[i].label;
+  *ms = 0.f;
+#ifndef DPC_EMU
+  hipError_t e = hipEventSynchronize(dpcprof::g_recs[i].b);
+  if (e != hipSuccess) return (int)e;
+  e = hipEventElapsedTime(ms, dpcprof::g_recs[i].a, dpcprof::g_recs[i].b);
+  if (e != hipSuccess) return (int)e;
+#endif
+  return DPC_OK;
+}
 
 size_t dpc_workspace_bytes(const DpcShape* shape, int direction) {
   if (check_shape(shape, false) != DPC_OK) return 0;
@@ -1128,10 +1250,10 @@ int dpc_transform_fwd(dpc_stream_t stream, const DpcShape* shape, const DpcParam
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid = point_grid(*shape), block(DPC_BLOCK, 1, 1);
   if (params->pose_is_quaternion)
-    DPC_LAUNCH((k_points_fwd<true>), grid, block, 0, st, *shape, *params, pc, pose, trans, focal, tr_pc,
+    DPC_LAUNCH("points_fwd", (k_points_fwd<true>), grid, block, 0, st, *shape, *params, pc, pose, trans, focal, tr_pc,
                (float*)nullptr);
   else
-    DPC_LAUNCH((k_points_fwd<false>), grid, block, 0, st, *shape, *params, pc, pose, trans, focal, tr_pc,
+    DPC_LAUNCH("points_fwd", (k_points_fwd<false>), grid, block, 0, st, *shape, *params, pc, pose, trans, focal, tr_pc,
                (float*)nullptr);
   return last_error();
 }
@@ -1152,9 +1274,9 @@ int dpc_voxelize_fwd(dpc_stream_t stream, const DpcShape* shape, const float* tr
   if (rc) return rc;
   if (!tr_pc || !grid) return DPC_E_NULL;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(grid, 0, grid_elems(*shape) * sizeof(float), st);
+  hipError_t e = dpc_memset("memset_grid", grid, grid_elems(*shape) * sizeof(float), st);
   if (e != hipSuccess) return (int)e;
-  DPC_LAUNCH((k_scatter), point_grid(*shape), dim3(DPC_BLOCK, 1, 1), 0, st, *shape, tr_pc, grid);
+  DPC_LAUNCH("scatter", (k_scatter), point_grid(*shape), dim3(DPC_BLOCK, 1, 1), 0, st, *shape, tr_pc, grid);
   return last_error();
 }
 
@@ -1163,7 +1285,7 @@ int dpc_voxelize_bwd(dpc_stream_t stream, const DpcShape* shape, const float* tr
   int rc = check_shape(shape, true);
   if (rc) return rc;
   if (!tr_pc || !dgrid || !dtr_pc) return DPC_E_NULL;
-  DPC_LAUNCH((k_gather), point_grid(*shape), dim3(DPC_BLOCK, 1, 1), 0, (hipStream_t)stream, *shape, tr_pc,
+  DPC_LAUNCH("gather", (k_gather), point_grid(*shape), dim3(DPC_BLOCK, 1, 1), 0, (hipStream_t)stream, *shape, tr_pc,
              dgrid, dtr_pc);
   return last_error();
 }
@@ -1216,7 +1338,7 @@ int dpc_max_collapse_fwd(dpc_stream_t stream, const DpcShape* shape, const float
   int rc = check_shape(shape, false);
   if (rc) return rc;
   if (!voxels || !proj) return DPC_E_NULL;
-  DPC_LAUNCH((k_max_fwd), col_grid(*shape, 1), dim3(DPC_BLOCK, 1, 1), 0, (hipStream_t)stream, voxels,
+  DPC_LAUNCH("max_fwd", (k_max_fwd), col_grid(*shape, 1), dim3(DPC_BLOCK, 1, 1), 0, (hipStream_t)stream, voxels,
              (const float*)nullptr, proj, shape->Dz, shape->D, flip_h);
   return last_error();
 }
@@ -1226,7 +1348,7 @@ int dpc_max_collapse_bwd(dpc_stream_t stream, const DpcShape* shape, const float
   int rc = check_shape(shape, false);
   if (rc) return rc;
   if (!voxels || !dproj || !dvoxels) return DPC_E_NULL;
-  DPC_LAUNCH((k_max_bwd), col_grid(*shape, 1), dim3(DPC_BLOCK, 1, 1), 0, (hipStream_t)stream, voxels,
+  DPC_LAUNCH("max_bwd", (k_max_bwd), col_grid(*shape, 1), dim3(DPC_BLOCK, 1, 1), 0, (hipStream_t)stream, voxels,
              (const float*)nullptr, dproj, dvoxels, (float*)nullptr, shape->Dz, shape->D, flip_h);
   return last_error();
 }
@@ -1254,14 +1376,14 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   float* tmp = (float*)workspace;
 
   // 1. zero G0, transform + scatter
-  hipError_t e = hipMemsetAsync(grid_raw, 0, grid_elems(S) * sizeof(float), st);
+  hipError_t e = dpc_memset("memset_grid", grid_raw, grid_elems(S) * sizeof(float), st);
   if (e != hipSuccess) return (int)e;
   {
     const dim3 grid = point_grid(S), block(DPC_BLOCK, 1, 1);
     if (P.pose_is_quaternion)
-      DPC_LAUNCH((k_points_fwd<true>), grid, block, 0, st, S, P, pc, pose, trans, focal, tr_pc, grid_raw);
+      DPC_LAUNCH("points_fwd", (k_points_fwd<true>), grid, block, 0, st, S, P, pc, pose, trans, focal, tr_pc, grid_raw);
     else
-      DPC_LAUNCH((k_points_fwd<false>), grid, block, 0, st, S, P, pc, pose, trans, focal, tr_pc, grid_raw);
+      DPC_LAUNCH("points_fwd", (k_points_fwd<false>), grid, block, 0, st, S, P, pc, pose, trans, focal, tr_pc, grid_raw);
     rc = last_error();
     if (rc) return rc;
   }
@@ -1297,7 +1419,7 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
                      clip_in, 1);
     if (rc) return rc;
   }
-  DPC_LAUNCH((k_max_fwd), col_grid(S, 1), dim3(DPC_BLOCK, 1, 1), 0, st, (const float*)grid_blur, scale, proj,
+  DPC_LAUNCH("max_fwd", (k_max_fwd), col_grid(S, 1), dim3(DPC_BLOCK, 1, 1), 0, st, (const float*)grid_blur, scale, proj,
              S.Dz, S.D, 1);
   return last_error();
 }
@@ -1329,7 +1451,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   float* accum = (float*)((char*)workspace + 2 * gbytes);
 
   if (dscale) {
-    hipError_t e = hipMemsetAsync(dscale, 0, sizeof(float) * (size_t)S.B, st);
+    hipError_t e = dpc_memset("memset_small", dscale, sizeof(float) * (size_t)S.B, st);
     if (e != hipSuccess) return (int)e;
   }
   // 1. collapse VJP (+ z-FIR adjoint) -> tA
@@ -1343,7 +1465,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
       rc = launch_zbwd(st, S, P, grid_blur, nullptr, 0, scale, ray_logt, dproj, dproj_depth, nullptr, first,
                        dscale, 1);
     } else {
-      DPC_LAUNCH((k_max_bwd), col_grid(S, 1), dim3(DPC_BLOCK, 1, 1), 0, st, grid_blur, scale, dproj, first,
+      DPC_LAUNCH("max_bwd", (k_max_bwd), col_grid(S, 1), dim3(DPC_BLOCK, 1, 1), 0, st, grid_blur, scale, dproj, first,
                  dscale, S.Dz, S.D, 1);
       rc = last_error();
     }

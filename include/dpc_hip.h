@@ -65,6 +65,20 @@ typedef struct DpcParams {
 
 const char* dpc_version(void);
 
+/* Optional per-kernel timing for benchmarking: while enabled, every kernel /
+ * memset the library enqueues is bracketed by HIP events recorded on the launch
+ * stream.  dpc_profile_get synchronises on record i and returns its label
+ * (static string, e.g. "zfwd") and elapsed milliseconds.  enable(…) clears
+ * the records.  Process-global; not for concurrent use. */
+int dpc_profile_enable(int on);
+int dpc_profile_count(void);
+int dpc_profile_get(int i, const char** label, float* ms);
+
+/* Diagnostic: grid-stride copy of n floats (n % 4 == 0) with `width` (1|2|4)
+ * floats per lane -- a kernel with exactly known HBM traffic (4n read, 4n
+ * written) used to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters. */
+int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, int width);
+
 /* Bytes of scratch `dpc_project_forward` (direction 0) / `dpc_project_backward`
  * (direction 1) need.  256-byte aligned device memory. */
 size_t dpc_workspace_bytes(const DpcShape* shape, int direction);

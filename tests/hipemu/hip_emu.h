@@ -113,7 +113,7 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 
-#define DPC_LAUNCH(kernel, grid, block, smem, stream, ...)                      \
+#define DPC_LAUNCH_RAW(kernel, grid, block, smem, stream, ...)                    \
   do {                                                                          \
     (void)(stream);                                                             \
     hipemu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); });    \

@@ -10,6 +10,7 @@ import torch
 
 from helpers import ALL_CASES, load, maxabs, relerr
 from run_case import run_product
+import parity_cases
 
 SMALL = [c for c in ALL_CASES if c not in ("mid", "cfg1")]
 GRAD_KEYS = ("dpc", "dpose", "dtrans", "dscale", "dfocal")
@@ -46,3 +47,19 @@ def test_emu_cfg1(emu):
     assert maxabs(res["proj_depth"], g["proj_depth_f64"]) < TOL_DEPTH
     for k in ("dpc", "dpose", "dscale"):
         assert relerr(gr[k], g[k + "_f64"]) < TOL_GRAD, k
+
+
+def test_emu_stage_level_api(emu):
+    parity_cases.stage_level_api_matches_cpu_oracle("cpu")
+
+
+@pytest.mark.parametrize("D,K", parity_cases.ODD_CASES)
+def test_emu_odd_sizes_and_generic_tap_counts(emu, D, K):
+    parity_cases.odd_sizes_and_generic_tap_counts("cpu", D, K)
+
+
+def test_emu_nan_points_dropped(emu):
+    g = load("tiny_nan")
+    res, _ = run_product("tiny_nan", g, "cpu", grads=False)
+    assert np.isfinite(res["proj"]).all()
+    assert maxabs(res["proj"], g["proj_f64"]) < TOL_PROJ
