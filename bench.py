@@ -124,42 +124,25 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dd = dpc_amd.distributed
+    rank, _, world = dd.env_world()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the projector has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    rank, world, device = dd.init("nccl")
 
     lib = dpc_amd.get_library()
     case = build_case(args.config, args.batch, device, seed_offset=1000 * rank)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step(case)
-    barrier()
+    dd.barrier(device)                      # barrier + torch.cuda.synchronize() on both sides
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(case)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    dd.barrier(device)
+    elapsed = dd.max_over_ranks(time.perf_counter() - t0, device)
 
     # ---- per-kernel durations (HIP events on the launch stream), rank 0 ----------
     roof = None
@@ -218,9 +201,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
         print(json.dumps(line))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    dd.finalize()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,169 @@
+"""CPU tier for the host side: the C-ABI library loads and exports every symbol
+include/dpc_hip.h declares, argument validation matches the reference's error
+behaviour, the product path refuses to run without its HIP library or on CPU
+tensors (no fallback), and the lazily materialised outputs behave like the
+reference's dict."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import dpc_amd
+from dpc_amd import _capi
+from helpers import ROOT, load, maxabs
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dpc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dpc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    decl = _declared_symbols()
+    assert "dpc_project_forward" in decl and "dpc_project_backward" in decl
+    assert sorted(_capi.SIGNATURES) == decl
+
+
+def test_hip_library_loads_and_exports_every_declared_symbol():
+    """No compute calls (there is no GPU here): load + symbol presence only."""
+    assert os.path.exists(_capi.LIB_PATH), "run `python __graft_entry__.py` (build) first"
+    dll = ctypes.CDLL(_capi.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(dll, name), name
+    lib = _capi.DpcLibrary(_capi.LIB_PATH)
+    assert "gfx950" in lib.version() and not lib.host_memory
+
+
+def test_hip_library_contains_gfx950_code_object():
+    blob = open(_capi.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"k_zfwd" in blob and b"k_blur_plane" in blob
+
+
+def test_c_abi_argument_validation_without_gpu():
+    """Status codes are produced before any launch, so they can be checked here."""
+    lib = _capi.DpcLibrary(_capi.LIB_PATH)
+    S = _capi.DpcShape(2, 10, 8, 8, 4, 5, 5)           # even Kx
+    P = _capi.DpcParams(2.0, 1.875, 1e-5, 10.0, 1, 0, 0)
+    assert lib.dpc_workspace_bytes(ctypes.byref(S), 0) == 0
+    S = _capi.DpcShape(2, 10, 8, 8, 5, 5, 5)
+    g = 2 * 8 * 8 * 8 * 4
+    assert lib.dpc_workspace_bytes(ctypes.byref(S), 0) == (g + 255) // 256 * 256
+    assert lib.dpc_workspace_bytes(ctypes.byref(S), 1) >= 2 * g
+    null = None
+    rc = lib.dpc_project_forward(null, ctypes.byref(S), ctypes.byref(P), *([null] * 14), null, 0)
+    assert rc == -1                                      # DPC_E_NULL
+    rc = lib.dpc_voxelize_fwd(null, ctypes.byref(_capi.DpcShape(0, 1, 8, 8, 0, 0, 0)), null, null)
+    assert rc == -2                                      # DPC_E_SHAPE
+    rc = lib.dpc_blur3d(null, ctypes.byref(_capi.DpcShape(1, 1, 8, 8, 0, 0, 65)), null, null, null, null, null, null, 0)
+    assert rc == -3                                      # DPC_E_TAPS
+    with pytest.raises(_capi.DpcError):
+        lib.check(-4, "x")
+
+
+def test_product_path_has_no_cpu_fallback():
+    prev = _capi.set_library(None)
+    try:
+        cfg = dpc_amd.default_config(vox_size=8)
+        pc = torch.zeros(1, 4, 3)
+        q = torch.tensor([[1.0, 0, 0, 0]])
+        with pytest.raises(ValueError, match="ROCm device"):
+            dpc_amd.pointcloud_project_fast(cfg, pc, q, None, None)
+        with pytest.raises(ValueError, match="ROCm device"):
+            dpc_amd.pointcloud2voxels3d_fast(cfg, pc, None)
+    finally:
+        _capi.set_library(prev)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    prev = _capi.set_library(None)
+    monkeypatch.setattr(_capi, "LIB_PATH", "/nonexistent/libdpc_hip.so")
+    try:
+        with pytest.raises(_capi.DpcError, match="not built"):
+            _capi.get_library()
+    finally:
+        _capi.set_library(prev)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "differentiable-point-clouds_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                for line in src.splitlines():
+                    ls = line.strip()
+                    if ls.startswith(("import ", "from ")):
+                        assert "oracle" not in ls and "hipemu" not in ls and "tf_shim" not in ls, (f, ls)
+
+
+# ---- argument checking mirrors the reference's graph-build-time errors ---------------
+def test_shape_and_type_errors(emu):
+    cfg = dpc_amd.default_config(vox_size=8, pc_gauss_kernel_size=3)
+    pc = torch.zeros(2, 5, 3)
+    with pytest.raises(ValueError, match="last dimension must be 4"):       # quaternion.py:22-29
+        dpc_amd.pointcloud_project_fast(cfg, pc, torch.zeros(2, 3), None, None)
+    with pytest.raises(ValueError):
+        dpc_amd.pointcloud_project_fast(cfg, torch.zeros(2, 5, 2), torch.ones(2, 4), None, None)
+    with pytest.raises(TypeError):
+        dpc_amd.pointcloud_project_fast(cfg, pc.double(), torch.ones(2, 4).double(), None, None)
+    with pytest.raises(NotImplementedError):                                   # RGB is 8(f) scope
+        dpc_amd.pointcloud_project_fast(cfg, pc, torch.ones(2, 4), None, torch.zeros(2, 5, 3))
+    cfg_m = dpc_amd.default_config(vox_size=8, pose_quaternion=False)
+    with pytest.raises(ValueError, match="quaternion pose"):                  # point_cloud.py:211-213
+        dpc_amd.pointcloud_project_fast(cfg_m, pc, torch.eye(4).repeat(2, 1, 1), torch.zeros(2, 3), None)
+    with pytest.raises(ValueError, match="even"):
+        dpc_amd.gauss_kernel_1d(4, 1.0, device="cpu")
+    cfg_bad = dpc_amd.default_config(vox_size=8, drc_logsum=False)
+    with pytest.raises(NotImplementedError):
+        dpc_amd.pointcloud_project_fast(cfg_bad, pc, torch.ones(2, 4), None, None)
+    with pytest.raises(KeyError):
+        dpc_amd.default_config(no_such_key=1)
+
+
+def test_empty_cloud_and_all_outliers(emu):
+    """Ragged/empty input: every point outside the cube -> background image,
+    zero point gradients."""
+    cfg = dpc_amd.default_config(vox_size=8, pc_gauss_kernel_size=3)
+    pc = torch.full((1, 6, 3), 0.9, requires_grad=True)
+    q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], requires_grad=True)
+    out = dpc_amd.pointcloud_project_fast(cfg, pc, q, None, None, dpc_amd.smoothing_kernel(cfg, 0.7, device="cpu"))
+    bg = 1 - (1 - 1e-5) ** 8
+    assert abs(float(out["proj"].max()) - bg) < 1e-7 and abs(float(out["proj"].min()) - bg) < 1e-7
+    out["proj"].sum().backward()
+    assert float(pc.grad.abs().max()) == 0.0
+
+
+def test_lazy_outputs_dict_semantics(emu):
+    g = load("tiny")
+    from run_case import product_cfg
+    cfg = product_cfg("tiny", g)
+    t = lambda k: torch.tensor(g[k])
+    kern = dpc_amd.smoothing_kernel(cfg, 0.8, device="cpu")
+    out = dpc_amd.pointcloud_project_fast(cfg, t("pc"), t("pose"), t("trans"), None, kern, scaling_factor=t("scale"))
+    assert set(out.keys()) == {"proj", "voxels", "tr_pc", "voxels_rgb", "proj_rgb", "drc_probs", "proj_depth"}
+    assert dict.__getitem__(out, "voxels") is None                  # not computed yet
+    v = out["voxels"]
+    assert v.shape == (2, 16, 16, 16, 1) and out["voxels"] is v     # computed once, cached
+    assert maxabs(v.numpy(), g["voxels_f64"]) < 2e-5
+    assert out["drc_probs"].shape == (17, 2, 16, 16, 1)
+    assert out["voxels_rgb"] is None and out["proj_rgb"] is None
+    assert out.get("proj") is out["proj"] and out.get("nope", 7) == 7
+
+
+def test_reference_filter_shapes_pick_the_axis(emu):
+    """smoothen_voxels3d reads the blur axis off the filter shape, so a caller
+    may pass the reference's [k_x,k_y,k_z] list in any order or a subset."""
+    cfg = dpc_amd.default_config(vox_size=8, pc_gauss_kernel_size=3)
+    vox = torch.rand(1, 8, 8, 8, 1)
+    kx, ky, kz = dpc_amd.smoothing_kernel(cfg, 0.9, device="cpu")
+    assert kx.shape == (1, 1, 3, 1, 1) and ky.shape == (1, 3, 1, 1, 1) and kz.shape == (3, 1, 1, 1, 1)
+    a = dpc_amd.smoothen_voxels3d(cfg, vox, [kx, ky, kz])
+    b = dpc_amd.smoothen_voxels3d(cfg, vox, [kz, kx, ky])
+    assert float((a - b).abs().max()) < 1e-6
+    only_z = dpc_amd.smoothen_voxels3d(cfg, vox, [kz])
+    ref = torch.nn.functional.conv3d(vox.permute(0, 4, 1, 2, 3), kz.reshape(1, 1, 3, 1, 1), padding=(1, 0, 0))
+    assert float((only_z.permute(0, 4, 1, 2, 3) - ref).abs().max()) < 1e-6
