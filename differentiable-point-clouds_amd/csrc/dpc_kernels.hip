@@ -421,8 +421,8 @@ __global__ void __launch_bounds__(DPC_BLOCK)
 k_points_fwd(DpcShape S, DpcParams P, const float* __restrict__ pc, const float* __restrict__ pose,
              const float* __restrict__ trans, const float* __restrict__ focal,
              float* __restrict__ tr_pc, float* __restrict__ grid /*nullable*/) {
-  const int b = blockIdx.y;
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.x;  // view-major block ids: b + B*chunk => one XCD (L2) per view when B % 8 == 0
+  const int n = blockIdx.y * blockDim.x + threadIdx.x;
   if (n >= S.N) return;
   Pose ps;
   load_pose<QUAT>(P, pose, trans, focal, b, ps);
@@ -437,8 +437,8 @@ k_points_fwd(DpcShape S, DpcParams P, const float* __restrict__ pc, const float*
 
 __global__ void __launch_bounds__(DPC_BLOCK)
 k_scatter(DpcShape S, const float* __restrict__ tr_pc, float* __restrict__ grid) {
-  const int b = blockIdx.y;
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.x;  // view-major block ids: b + B*chunk => one XCD (L2) per view when B % 8 == 0
+  const int n = blockIdx.y * blockDim.x + threadIdx.x;
   if (n >= S.N) return;
   const size_t o = ((size_t)b * S.N + n) * 3;
   scatter_point(grid, b, S.Dz, S.D, tr_pc[o], tr_pc[o + 1], tr_pc[o + 2]);
@@ -447,8 +447,8 @@ k_scatter(DpcShape S, const float* __restrict__ tr_pc, float* __restrict__ grid)
 __global__ void __launch_bounds__(DPC_BLOCK)
 k_gather(DpcShape S, const float* __restrict__ tr_pc, const float* __restrict__ dgrid,
          float* __restrict__ dtr_pc) {
-  const int b = blockIdx.y;
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.x;  // view-major block ids: b + B*chunk => one XCD (L2) per view when B % 8 == 0
+  const int n = blockIdx.y * blockDim.x + threadIdx.x;
   if (n >= S.N) return;
   const size_t o = ((size_t)b * S.N + n) * 3;
   float dw, dv, du;
@@ -468,8 +468,8 @@ k_points_bwd(DpcShape S, DpcParams P, const float* __restrict__ pc, const float*
              const float* __restrict__ mask, const float* __restrict__ taps_x,
              const float* __restrict__ dtr_in /*nullable when GATHER*/, float* __restrict__ dpc,
              float* __restrict__ accum /*[B,16], zeroed*/) {
-  const int b = blockIdx.y;
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.x;  // view-major block ids: b + B*chunk => one XCD (L2) per view when B % 8 == 0
+  const int n = blockIdx.y * blockDim.x + threadIdx.x;
   float acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -706,6 +706,122 @@ struct ZFir {
   }
 };
 
+
+// ===========================================================================
+// plane blur, streaming form (power-of-two D <= 256): no LDS, no barriers.
+// Lanes lie along x with 4 floats each; a row is LR = D/4 lanes, so one wave
+// covers 64/LR planes side by side and marches down y.  The x-blur pulls its
+// halo from neighbour lanes with ds_bpermute (__shfl); the y-blur is a register
+// FIR in accumulate form (same ZFir as the z kernels).  Rows are prefetched PF
+// ahead so every lane keeps PF 16-byte loads in flight.
+// ===========================================================================
+#define DPC_XY_PF 4
+
+template <int KC, bool DO_X, bool DO_Y>
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_blur_xy_stream(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ taps_x,
+                 const float* __restrict__ taps_y, int nplanes, int D, int lr_shift, int clip_in) {
+  constexpr int h = KC / 2;
+  constexpr int PF = DPC_XY_PF;
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int LR = 1 << lr_shift;
+  const int sub = lane >> lr_shift;
+  const int lx = lane & (LR - 1);
+  const int plane = wave * (64 >> lr_shift) + sub;
+  const bool ok = plane < nplanes;
+  const size_t pbase = (size_t)(ok ? plane : 0) * D * D + (size_t)lx * 4;
+  float tpx[KC];
+#pragma unroll
+  for (int m = 0; m < KC; ++m) tpx[m] = DO_X ? taps_x[m] : 0.f;
+  ZFir<KC, 4> fir;
+  fir.init(DO_Y ? taps_y : nullptr);
+  const int T = D + (DO_Y ? h : 0);
+
+  float cur[PF][4], nxt[PF][4];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    if (ok && u < D) {
+      load_cx<4>(in + pbase + (size_t)u * D, cur[u]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) cur[u][c] = 0.f;
+    }
+  }
+  for (int y0 = 0; y0 < T; y0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int yy = y0 + PF + u;
+      if (ok && yy < D) {
+        load_cx<4>(in + pbase + (size_t)yy * D, nxt[u]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) nxt[u][c] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int y = y0 + u;
+      if (y < T) {  // uniform
+        float v[4], xb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = clip_in ? clampf(cur[u][c], 0.f, 1.f) : cur[u][c];
+        if (DO_X && y < D) {
+          float w[4 + 2 * h];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) w[h + c] = v[c];
+#pragma unroll
+          for (int e = 1; e <= h; ++e) {
+            // left halo element x = 4*lx - e ; right halo element x = 4*lx + 3 + e
+            const int dl = (e + 3) / 4;            // lanes to the left
+            const int jl = (4 * dl - e) & 3;       // element index inside that lane
+            const float vl = __shfl(v[jl], (lane - dl) & 63, 64);
+            w[h - e] = (lx - dl >= 0) ? vl : 0.f;
+            const int dr = (e + 3) / 4;
+            const int jr = (e - 1) & 3;
+            const float vr = __shfl(v[jr], (lane + dr) & 63, 64);
+            w[h + 3 + e] = (lx + dr < LR) ? vr : 0.f;
+          }
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            float a = 0.f;
+#pragma unroll
+            for (int m = 0; m < KC; ++m) a += tpx[m] * w[o + m];
+            xb[o] = a;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) xb[c] = (y < D) ? v[c] : 0.f;
+        }
+        if (DO_Y) {
+          float o[4];
+          fir.push(xb, o, false);
+          if (y >= h && ok) store_cx<4>(out + pbase + (size_t)(y - h) * D, o);
+        } else {
+          if (ok) store_cx<4>(out + pbase + (size_t)y * D, xb);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) cur[u][c] = nxt[u][c];
+  }
+}
+
+// plane `t` of a ray bundle (zeros outside [0,Dz)); DPC_Z_PF planes are kept
+// in flight per lane by the z kernels' software prefetch
+#define DPC_Z_PF 4
+template <int CX>
+__device__ __forceinline__ void zload(const float* __restrict__ base, int ncol, int t, int Dz, float (&v)[CX]) {
+  if (t >= 0 && t < Dz) {
+    load_cx<CX>(base + (size_t)t * ncol, v);
+  } else {
+#pragma unroll
+    for (int c = 0; c < CX; ++c) v[c] = 0.f;
+  }
+}
+
 // plain z blur, compile-time K
 template <int KC, int CX>
 __global__ void __launch_bounds__(DPC_BLOCK)
@@ -719,16 +835,27 @@ k_blur_z(const float* __restrict__ in, float* __restrict__ out, const float* __r
   constexpr int h = KC / 2;
   ZFir<KC, CX> fir;
   fir.init(taps);
-  for (int t = 0; t < Dz + h; ++t) {
-    float v[CX], o[CX];
-    if (t < Dz) {
-      load_cx<CX>(in + base + (size_t)t * ncol, v);
-    } else {
+  constexpr int PF = DPC_Z_PF;
+  const int T = Dz + h;
+  float cur[PF][CX], nxt[PF][CX];
 #pragma unroll
-      for (int c = 0; c < CX; ++c) v[c] = 0.f;
+  for (int u = 0; u < PF; ++u) zload<CX>(in + base, ncol, u, Dz, cur[u]);
+  for (int t0 = 0; t0 < T; t0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) zload<CX>(in + base, ncol, t0 + PF + u, Dz, nxt[u]);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int t = t0 + u;
+      if (t < T) {
+        float o[CX];
+        fir.push(cur[u], o, false);
+        if (t >= h) store_cx<CX>(out + base + (size_t)(t - h) * ncol, o);
+      }
     }
-    fir.push(v, o, false);
-    if (t >= h) store_cx<CX>(out + base + (size_t)(t - h) * ncol, o);
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+      for (int c = 0; c < CX; ++c) cur[u][c] = nxt[u][c];
   }
 }
 
@@ -787,38 +914,48 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
     dp[c] = 0.f;
     Sd[c] = 0.0;
   }
-  for (int t = 0; t < Dz + h; ++t) {
-    float v[CX], g2[CX];
-    if (t < Dz) {
-      load_cx<CX>(in + base + (size_t)t * ncol, v);
-      if (clip_in) {
+  constexpr int PF = DPC_Z_PF;
+  const int T = Dz + h;
+  float cur[PF][CX], nxt[PF][CX];
 #pragma unroll
-        for (int c = 0; c < CX; ++c) v[c] = clampf(v[c], 0.f, 1.f);
+  for (int u = 0; u < PF; ++u) zload<CX>(in + base, ncol, u, Dz, cur[u]);
+  for (int t0 = 0; t0 < T; t0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) zload<CX>(in + base, ncol, t0 + PF + u, Dz, nxt[u]);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int t = t0 + u;
+      if (t < T) {
+        float v[CX], g2[CX];
+#pragma unroll
+        for (int c = 0; c < CX; ++c) v[c] = (clip_in && t < Dz) ? clampf(cur[u][c], 0.f, 1.f) : cur[u][c];
+        fir.push(v, g2, false);
+        if (t >= h) {
+          const int o = t - h;
+          if (g2_out) store_cx<CX>(g2_out + base + (size_t)o * ncol, g2);
+          const float psi = (float)o / fDz - 0.5f + P.camera_distance;
+          float pv[CX];
+#pragma unroll
+          for (int c = 0; c < CX; ++c) {
+            const float g3 = has_s ? clampf(g2[c] * s, 0.f, 1.f) : g2[c];
+            const float cc = clampf(g3, eps, one_m);
+            const float ly = logf(cc);
+            const float lx = logf(1.0f - cc);
+            const float p = expf((o == 0 ? eps : S[c]) + ly);  // "unity" is eps (drc.py:58-59)
+            pv[c] = p;
+            pj[c] += p;
+            dp[c] += p * psi;
+            S[c] += lx;
+            Sd[c] += (double)lx;
+          }
+          if (probs) store_cx<CX>(probs + ((size_t)o * B + b) * ncol + ocol, pv);
+        }
       }
-    } else {
-#pragma unroll
-      for (int c = 0; c < CX; ++c) v[c] = 0.f;
     }
-    fir.push(v, g2, false);
-    if (t < h) continue;
-    const int o = t - h;
-    if (g2_out) store_cx<CX>(g2_out + base + (size_t)o * ncol, g2);
-    const float psi = (float)o / fDz - 0.5f + P.camera_distance;
-    float pv[CX];
 #pragma unroll
-    for (int c = 0; c < CX; ++c) {
-      const float g3 = has_s ? clampf(g2[c] * s, 0.f, 1.f) : g2[c];
-      const float cc = clampf(g3, eps, one_m);
-      const float ly = logf(cc);
-      const float lx = logf(1.0f - cc);
-      const float p = expf((o == 0 ? eps : S[c]) + ly);  // "unity" is eps (drc.py:58-59)
-      pv[c] = p;
-      pj[c] += p;
-      dp[c] += p * psi;
-      S[c] += lx;
-      Sd[c] += (double)lx;
-    }
-    if (probs) store_cx<CX>(probs + ((size_t)o * B + b) * ncol + ocol, pv);
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+      for (int c = 0; c < CX; ++c) cur[u][c] = nxt[u][c];
   }
   float pl[CX];
 #pragma unroll
@@ -895,44 +1032,60 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
     }
     ZFir<KC, CX> fir;
     fir.init(taps);
-    for (int t = 0; t < Dz + h; ++t) {
-      const int j = Dz - 1 - t;
-      float dg2[CX], o[CX];
-      if (j >= 0) {
-        float v[CX];
-        load_cx<CX>(g2_in + base + (size_t)j * ncol, v);
-        const float psi = (float)j / fDz - 0.5f + P.camera_distance;
+    constexpr int PF = DPC_Z_PF;
+    const int T = Dz + h;
+    float cur[PF][CX], nxt[PF][CX];
 #pragma unroll
-        for (int c = 0; c < CX; ++c) {
-          const float sg = v[c] * s;
-          const float g3 = has_s ? clampf(sg, 0.f, 1.f) : v[c];
-          const float cc = clampf(g3, eps, one_m);
-          const float ly = logf(cc);
-          const float omc = 1.0f - cc;
-          const float lx = logf(omc);
-          R[c] += (double)lx;
-          const float Sj = (float)(St[c] - R[c]);
-          const float p = expf((j == 0 ? eps : Sj) + ly);
-          float gam = g[c] + gd[c] * psi;
-          if (dprobs) gam += dprobs[((size_t)j * B + b) * ncol + ocol + c];
-          const float a = gam * p;
-          const float dc = a / cc - suffix[c] / omc;
-          const float dg3 = (g3 >= eps && g3 <= one_m) ? dc : 0.f;
-          suffix[c] += a;
-          if (has_s) {
-            const bool m2 = (sg >= 0.f) && (sg <= 1.f);
-            dg2[c] = m2 ? s * dg3 : 0.f;
-            dsacc[0] += m2 ? v[c] * dg3 : 0.f;
+    for (int u = 0; u < PF; ++u) zload<CX>(g2_in + base, ncol, Dz - 1 - u, Dz, cur[u]);
+    for (int t0 = 0; t0 < T; t0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) zload<CX>(g2_in + base, ncol, Dz - 1 - (t0 + PF + u), Dz, nxt[u]);
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int t = t0 + u;
+        if (t < T) {
+          const int j = Dz - 1 - t;
+          float dg2[CX], o[CX];
+          if (j >= 0) {
+            const float psi = (float)j / fDz - 0.5f + P.camera_distance;
+#pragma unroll
+            for (int c = 0; c < CX; ++c) {
+              const float vv = cur[u][c];
+              const float sg = vv * s;
+              const float g3 = has_s ? clampf(sg, 0.f, 1.f) : vv;
+              const float cc = clampf(g3, eps, one_m);
+              const float ly = logf(cc);
+              const float omc = 1.0f - cc;
+              const float lx = logf(omc);
+              R[c] += (double)lx;
+              const float Sj = (float)(St[c] - R[c]);
+              const float p = expf((j == 0 ? eps : Sj) + ly);
+              float gam = g[c] + gd[c] * psi;
+              if (dprobs) gam += dprobs[((size_t)j * B + b) * ncol + ocol + c];
+              const float a = gam * p;
+              const float dc = a / cc - suffix[c] / omc;
+              const float dg3 = (g3 >= eps && g3 <= one_m) ? dc : 0.f;
+              suffix[c] += a;
+              if (has_s) {
+                const bool m2 = (sg >= 0.f) && (sg <= 1.f);
+                dg2[c] = m2 ? s * dg3 : 0.f;
+                dsacc[0] += m2 ? vv * dg3 : 0.f;
+              } else {
+                dg2[c] = dg3;
+              }
+            }
           } else {
-            dg2[c] = dg3;
-          }
-        }
-      } else {
 #pragma unroll
-        for (int c = 0; c < CX; ++c) dg2[c] = 0.f;
+            for (int c = 0; c < CX; ++c) dg2[c] = 0.f;
+          }
+          fir.push(dg2, o, true);
+          if (t >= h) store_cx<CX>(dgz + base + (size_t)(j + h) * ncol, o);
+        }
       }
-      fir.push(dg2, o, true);
-      if (t >= h) store_cx<CX>(dgz + base + (size_t)(j + h) * ncol, o);
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int c = 0; c < CX; ++c) cur[u][c] = nxt[u][c];
     }
   }
   if (dscale) {  // uniform across the grid
@@ -1025,7 +1178,7 @@ namespace {
 int check_shape(const DpcShape* S, bool need_points) {
   if (!S) return DPC_E_NULL;
   if (S->B <= 0 || S->Dz <= 0 || S->D <= 0 || S->B > 65535) return DPC_E_SHAPE;
-  if (need_points && S->N <= 0) return DPC_E_SHAPE;
+  if (need_points && (S->N <= 0 || S->N > 65535 * DPC_BLOCK)) return DPC_E_SHAPE;
   if ((long long)S->D * S->D > (1 << 20) || S->Dz > 4096) return DPC_E_SHAPE;
   const int ks[3] = {S->Kx, S->Ky, S->Kz};
   for (int i = 0; i < 3; ++i) {
@@ -1043,11 +1196,49 @@ inline int last_error() {
   return e == hipSuccess ? DPC_OK : (int)e;
 }
 
-inline dim3 point_grid(const DpcShape& S) { return dim3((S.N + DPC_BLOCK - 1) / DPC_BLOCK, S.B, 1); }
+inline dim3 point_grid(const DpcShape& S) { return dim3(S.B, (S.N + DPC_BLOCK - 1) / DPC_BLOCK, 1); }
 
 // ---- plane blur launch -------------------------------------------------------
+// streaming (LDS-free) plane blur: D a power of two in [16,256], K in {5,11,21}
+bool launch_blur_xy_stream(hipStream_t st, const DpcShape& S, const float* in, float* out, const float* tx,
+                           const float* ty, int Kx, int Ky, int clip_in, int* rc) {
+  const int D = S.D;
+  if (D < 16 || D > 256 || (D & (D - 1)) != 0) return false;
+  if (!(Kx == 0 || Ky == 0 || Kx == Ky)) return false;
+  const int K = Kx > 0 ? Kx : Ky;
+  if (K != 5 && K != 11 && K != 21) return false;
+  int lr_shift = 0;
+  while ((4 << lr_shift) < D) ++lr_shift;
+  const int PL = 64 >> lr_shift;
+  const long long nplanes = (long long)S.B * S.Dz;
+  const long long nwaves = (nplanes + PL - 1) / PL;
+  const long long nblk = (nwaves + (DPC_BLOCK / 64) - 1) / (DPC_BLOCK / 64);
+  if (nblk > 0x7fffffffLL) return false;
+  const dim3 grid((unsigned)nblk, 1, 1), block(DPC_BLOCK, 1, 1);
+#define DPC_XY(KC, X, Y)                                                                             \
+  DPC_LAUNCH("blur_xy", (k_blur_xy_stream<KC, X, Y>), grid, block, 0, st, in, out, tx, ty, (int)nplanes, D, \
+             lr_shift, clip_in)
+#define DPC_XY_K(KC)                          \
+  do {                                        \
+    if (Kx > 0 && Ky > 0) DPC_XY(KC, true, true);   \
+    else if (Kx > 0) DPC_XY(KC, true, false); \
+    else DPC_XY(KC, false, true);             \
+  } while (0)
+  if (K == 5) DPC_XY_K(5);
+  else if (K == 11) DPC_XY_K(11);
+  else DPC_XY_K(21);
+#undef DPC_XY_K
+#undef DPC_XY
+  *rc = last_error();
+  return true;
+}
+
 int launch_blur_plane(hipStream_t st, const DpcShape& S, const float* in, float* out, const float* tx,
                       const float* ty, int Kx, int Ky, int clip_in) {
+  {
+    int rc = DPC_OK;
+    if (launch_blur_xy_stream(st, S, in, out, tx, ty, Kx, Ky, clip_in, &rc)) return rc;
+  }
   const int D = S.D;
   const int hx = Kx / 2, hy = Ky / 2;
   const int nxc = (D + DPC_XC - 1) / DPC_XC;

@@ -94,6 +94,18 @@ static inline float __shfl_down(float v, unsigned delta, int width = 64) {
   hipemu::sync();
   return r;
 }
+static inline float __shfl(float v, int src_lane, int width = 64) {
+  (void)width;
+  unsigned f = hipemu::t_ctx.flat;
+  memcpy(&hipemu::g_xchg[f], &v, 4);
+  hipemu::sync();
+  unsigned nthreads = hipemu::t_ctx.bdim.x * hipemu::t_ctx.bdim.y * hipemu::t_ctx.bdim.z;
+  unsigned src = (f & ~63u) | ((unsigned)src_lane & 63u);
+  float r = v;
+  if (src < nthreads) memcpy(&r, &hipemu::g_xchg[src], 4);
+  hipemu::sync();
+  return r;
+}
 static inline float __shfl_xor(float v, int mask, int width = 64) {
   (void)width;
   unsigned f = hipemu::t_ctx.flat;
