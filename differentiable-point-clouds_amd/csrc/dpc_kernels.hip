@@ -675,6 +675,10 @@ __device__ __forceinline__ void store_cx(float* __restrict__ p, const float (&v)
 
 // Register FIR in "accumulate" form: pushing input plane t completes output
 // plane t - h (zero padding falls out because only real planes are pushed).
+// The K partial sums live in a ROTATING set of registers: inside a loop body
+// unrolled over a group of G steps (G a multiple of K) the slot of logical
+// accumulator k at step u is (k + u) % K, a compile-time constant, so no
+// register-to-register shifting is ever executed.
 template <int KC, int CX>
 struct ZFir {
   float acc[KC][CX];
@@ -687,42 +691,38 @@ struct ZFir {
       for (int c = 0; c < CX; ++c) acc[j][c] = 0.f;
     }
   }
-  // reversed=true: planes arrive in descending order (adjoint walk)
-  __device__ __forceinline__ void push(const float (&v)[CX], float (&out)[CX], bool reversed) {
+  // u = step index inside the unrolled group (compile-time after unrolling)
+  __device__ __forceinline__ void push(const float (&v)[CX], float (&out)[CX], int u) {
 #pragma unroll
-    for (int j = 0; j < KC; ++j) {
-      const float t = reversed ? tp[j] : tp[KC - 1 - j];
+    for (int k = 0; k < KC; ++k) {
+      const float t = tp[KC - 1 - k];
 #pragma unroll
-      for (int c = 0; c < CX; ++c) acc[j][c] += t * v[c];
+      for (int c = 0; c < CX; ++c) acc[(k + u) % KC][c] += t * v[c];
     }
 #pragma unroll
-    for (int c = 0; c < CX; ++c) out[c] = acc[0][c];
-#pragma unroll
-    for (int j = 0; j + 1 < KC; ++j)
-#pragma unroll
-      for (int c = 0; c < CX; ++c) acc[j][c] = acc[j + 1][c];
-#pragma unroll
-    for (int c = 0; c < CX; ++c) acc[KC - 1][c] = 0.f;
+    for (int c = 0; c < CX; ++c) {
+      out[c] = acc[u % KC][c];
+      acc[u % KC][c] = 0.f;
+    }
   }
 };
-
+// group length: a multiple of KC, at least 4 planes/rows (= loads kept in flight per lane)
+constexpr int zgroup(int KC) { return KC >= 4 ? KC : KC * ((4 + KC - 1) / KC); }
 
 // ===========================================================================
 // plane blur, streaming form (power-of-two D <= 256): no LDS, no barriers.
 // Lanes lie along x with 4 floats each; a row is LR = D/4 lanes, so one wave
 // covers 64/LR planes side by side and marches down y.  The x-blur pulls its
 // halo from neighbour lanes with ds_bpermute (__shfl); the y-blur is a register
-// FIR in accumulate form (same ZFir as the z kernels).  Rows are prefetched PF
-// ahead so every lane keeps PF 16-byte loads in flight.
+// FIR (ZFir).  A whole group of rows is loaded (unconditionally, from clamped
+// addresses) one group ahead, so every lane keeps G 16-byte loads in flight.
 // ===========================================================================
-#define DPC_XY_PF 4
-
 template <int KC, bool DO_X, bool DO_Y>
 __global__ void __launch_bounds__(DPC_BLOCK)
 k_blur_xy_stream(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ taps_x,
                  const float* __restrict__ taps_y, int nplanes, int D, int lr_shift, int clip_in) {
   constexpr int h = KC / 2;
-  constexpr int PF = DPC_XY_PF;
+  constexpr int G = zgroup(KC);
   const int lane = threadIdx.x & 63;
   const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int LR = 1 << lr_shift;
@@ -738,34 +738,25 @@ k_blur_xy_stream(const float* __restrict__ in, float* __restrict__ out, const fl
   fir.init(DO_Y ? taps_y : nullptr);
   const int T = D + (DO_Y ? h : 0);
 
-  float cur[PF][4], nxt[PF][4];
+  float cur[G][4], nxt[G][4];
 #pragma unroll
-  for (int u = 0; u < PF; ++u) {
-    if (ok && u < D) {
-      load_cx<4>(in + pbase + (size_t)u * D, cur[u]);
-    } else {
+  for (int u = 0; u < G; ++u) load_cx<4>(in + pbase + (size_t)(u < D ? u : D - 1) * D, cur[u]);
+  for (int y0 = 0; y0 < T; y0 += G) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) cur[u][c] = 0.f;
-    }
-  }
-  for (int y0 = 0; y0 < T; y0 += PF) {
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int yy = y0 + PF + u;
-      if (ok && yy < D) {
-        load_cx<4>(in + pbase + (size_t)yy * D, nxt[u]);
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) nxt[u][c] = 0.f;
-      }
+    for (int u = 0; u < G; ++u) {
+      const int yy = y0 + G + u;
+      load_cx<4>(in + pbase + (size_t)(yy < D ? yy : D - 1) * D, nxt[u]);
     }
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
+    for (int u = 0; u < G; ++u) {
       const int y = y0 + u;
       if (y < T) {  // uniform
         float v[4], xb[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = clip_in ? clampf(cur[u][c], 0.f, 1.f) : cur[u][c];
+        for (int c = 0; c < 4; ++c) {
+          const float r = (y < D) ? cur[u][c] : 0.f;
+          v[c] = clip_in ? clampf(r, 0.f, 1.f) : r;
+        }
         if (DO_X && y < D) {
           float w[4 + 2 * h];
 #pragma unroll
@@ -773,14 +764,13 @@ k_blur_xy_stream(const float* __restrict__ in, float* __restrict__ out, const fl
 #pragma unroll
           for (int e = 1; e <= h; ++e) {
             // left halo element x = 4*lx - e ; right halo element x = 4*lx + 3 + e
-            const int dl = (e + 3) / 4;            // lanes to the left
-            const int jl = (4 * dl - e) & 3;       // element index inside that lane
+            const int dl = (e + 3) / 4;       // lanes to the left / right
+            const int jl = (4 * dl - e) & 3;  // element index inside that lane
             const float vl = __shfl(v[jl], (lane - dl) & 63, 64);
             w[h - e] = (lx - dl >= 0) ? vl : 0.f;
-            const int dr = (e + 3) / 4;
             const int jr = (e - 1) & 3;
-            const float vr = __shfl(v[jr], (lane + dr) & 63, 64);
-            w[h + 3 + e] = (lx + dr < LR) ? vr : 0.f;
+            const float vr = __shfl(v[jr], (lane + dl) & 63, 64);
+            w[h + 3 + e] = (lx + dl < LR) ? vr : 0.f;
           }
 #pragma unroll
           for (int o = 0; o < 4; ++o) {
@@ -791,11 +781,11 @@ k_blur_xy_stream(const float* __restrict__ in, float* __restrict__ out, const fl
           }
         } else {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) xb[c] = (y < D) ? v[c] : 0.f;
+          for (int c = 0; c < 4; ++c) xb[c] = v[c];
         }
         if (DO_Y) {
           float o[4];
-          fir.push(xb, o, false);
+          fir.push(xb, o, u);
           if (y >= h && ok) store_cx<4>(out + pbase + (size_t)(y - h) * D, o);
         } else {
           if (ok) store_cx<4>(out + pbase + (size_t)y * D, xb);
@@ -803,23 +793,19 @@ k_blur_xy_stream(const float* __restrict__ in, float* __restrict__ out, const fl
       }
     }
 #pragma unroll
-    for (int u = 0; u < PF; ++u)
+    for (int u = 0; u < G; ++u)
 #pragma unroll
       for (int c = 0; c < 4; ++c) cur[u][c] = nxt[u][c];
   }
 }
 
-// plane `t` of a ray bundle (zeros outside [0,Dz)); DPC_Z_PF planes are kept
-// in flight per lane by the z kernels' software prefetch
-#define DPC_Z_PF 4
+// plane `t` of a ray bundle, loaded unconditionally from a clamped address
+// (so the compiler can keep a whole group of loads in flight); the caller
+// zeroes it when t is outside [0,Dz)
 template <int CX>
 __device__ __forceinline__ void zload(const float* __restrict__ base, int ncol, int t, int Dz, float (&v)[CX]) {
-  if (t >= 0 && t < Dz) {
-    load_cx<CX>(base + (size_t)t * ncol, v);
-  } else {
-#pragma unroll
-    for (int c = 0; c < CX; ++c) v[c] = 0.f;
-  }
+  const int tc = t < 0 ? 0 : (t < Dz ? t : Dz - 1);
+  load_cx<CX>(base + (size_t)tc * ncol, v);
 }
 
 // plain z blur, compile-time K
@@ -833,27 +819,29 @@ k_blur_z(const float* __restrict__ in, float* __restrict__ out, const float* __r
   if (col >= ncol) return;
   const size_t base = (size_t)b * Dz * ncol + col;
   constexpr int h = KC / 2;
+  constexpr int G = zgroup(KC);
   ZFir<KC, CX> fir;
   fir.init(taps);
-  constexpr int PF = DPC_Z_PF;
   const int T = Dz + h;
-  float cur[PF][CX], nxt[PF][CX];
+  float cur[G][CX], nxt[G][CX];
 #pragma unroll
-  for (int u = 0; u < PF; ++u) zload<CX>(in + base, ncol, u, Dz, cur[u]);
-  for (int t0 = 0; t0 < T; t0 += PF) {
+  for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, u, Dz, cur[u]);
+  for (int t0 = 0; t0 < T; t0 += G) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u) zload<CX>(in + base, ncol, t0 + PF + u, Dz, nxt[u]);
+    for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, t0 + G + u, Dz, nxt[u]);
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
+    for (int u = 0; u < G; ++u) {
       const int t = t0 + u;
       if (t < T) {
-        float o[CX];
-        fir.push(cur[u], o, false);
+        float v[CX], o[CX];
+#pragma unroll
+        for (int c = 0; c < CX; ++c) v[c] = (t < Dz) ? cur[u][c] : 0.f;
+        fir.push(v, o, u);
         if (t >= h) store_cx<CX>(out + base + (size_t)(t - h) * ncol, o);
       }
     }
 #pragma unroll
-    for (int u = 0; u < PF; ++u)
+    for (int u = 0; u < G; ++u)
 #pragma unroll
       for (int c = 0; c < CX; ++c) cur[u][c] = nxt[u][c];
   }
@@ -879,17 +867,27 @@ k_blur_z_generic(const float* __restrict__ in, float* __restrict__ out, const fl
   }
 }
 
-// Forward: z-FIR + (scale, clip) + log-space DRC collapse (drc.py:47-123) +
-// depth (drc.py:139-153), streaming each ray once.
+// ---------------------------------------------------------------------------
+// Ray collapse (drc.py:47-123), transcendental-free: with c_j = clip(G3_j, eps,
+// 1-eps) the reference's p_j = exp(sum_{i<j} log(1-c_i) + log c_j) is the
+// product T_j c_j with T_{j+1} = T_j (1 - c_j) (identical up to fp32 rounding);
+// its quirks are kept: the "unity" of the log-space prefix is eps, so
+// p_0 = e^eps c_0 and p_Dz = e^eps T_Dz (drc.py:58-59,92-96).
+// Forward also leaves two float64 sums per ray for the backward pass:
+//   P = sum_{j<Dz} p_j,   Q = sum_{j<=Dz} p_j psi_j.
+// ---------------------------------------------------------------------------
+
+// Forward: z-FIR + (scale, clip) + DRC collapse + depth (drc.py:139-153),
+// streaming each ray once.
 //   in      xy-blurred grid (or raw grid with clip_in when there is no blur)
 //   g2_out  post-blur grid G2, saved for backward            (nullable)
 //   probs   event probabilities [Dz+1,B,D,D]                 (nullable)
-//   proj/depth [B,D,D] (flip_h: image row D-1-y); logt [B,D,D] double, row y
+//   proj/depth [B,D,D] (flip_h: image row D-1-y); sums [B,D,D,2] double, row y
 template <int KC, int CX>
 __global__ void __launch_bounds__(DPC_BLOCK)
 k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps,
        const float* __restrict__ scale, float* __restrict__ g2_out, float* __restrict__ probs,
-       float* __restrict__ proj, float* __restrict__ depth, double* __restrict__ logt, int B, int Dz,
+       float* __restrict__ proj, float* __restrict__ depth, double* __restrict__ sums, int B, int Dz,
        int D, int clip_in, int flip_h) {
   const int b = blockIdx.y;
   const int ncol = D * D;
@@ -899,37 +897,40 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
   const int y = col / D, x0 = col - y * D;
   const int ocol = (flip_h ? (D - 1 - y) : y) * D + x0;
   constexpr int h = KC / 2;
+  constexpr int G = zgroup(KC);
   const float eps = P.eps, one_m = 1.0f - P.eps;
+  const float e_eps = expf(eps);
   const bool has_s = scale != nullptr;
   const float s = has_s ? scale[b] : 1.0f;
   const float fDz = (float)Dz;
   ZFir<KC, CX> fir;
   fir.init(taps);
-  float S[CX], pj[CX], dp[CX];
-  double Sd[CX];
+  float Tr[CX];
+  double Ps[CX], Qs[CX];
 #pragma unroll
   for (int c = 0; c < CX; ++c) {
-    S[c] = 0.f;
-    pj[c] = 0.f;
-    dp[c] = 0.f;
-    Sd[c] = 0.0;
+    Tr[c] = 1.0f;
+    Ps[c] = 0.0;
+    Qs[c] = 0.0;
   }
-  constexpr int PF = DPC_Z_PF;
   const int T = Dz + h;
-  float cur[PF][CX], nxt[PF][CX];
+  float cur[G][CX], nxt[G][CX];
 #pragma unroll
-  for (int u = 0; u < PF; ++u) zload<CX>(in + base, ncol, u, Dz, cur[u]);
-  for (int t0 = 0; t0 < T; t0 += PF) {
+  for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, u, Dz, cur[u]);
+  for (int t0 = 0; t0 < T; t0 += G) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u) zload<CX>(in + base, ncol, t0 + PF + u, Dz, nxt[u]);
+    for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, t0 + G + u, Dz, nxt[u]);
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
+    for (int u = 0; u < G; ++u) {
       const int t = t0 + u;
       if (t < T) {
         float v[CX], g2[CX];
 #pragma unroll
-        for (int c = 0; c < CX; ++c) v[c] = (clip_in && t < Dz) ? clampf(cur[u][c], 0.f, 1.f) : cur[u][c];
-        fir.push(v, g2, false);
+        for (int c = 0; c < CX; ++c) {
+          const float r = (t < Dz) ? cur[u][c] : 0.f;
+          v[c] = clip_in ? clampf(r, 0.f, 1.f) : r;
+        }
+        fir.push(v, g2, u);
         if (t >= h) {
           const int o = t - h;
           if (g2_out) store_cx<CX>(g2_out + base + (size_t)o * ncol, g2);
@@ -939,49 +940,52 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
           for (int c = 0; c < CX; ++c) {
             const float g3 = has_s ? clampf(g2[c] * s, 0.f, 1.f) : g2[c];
             const float cc = clampf(g3, eps, one_m);
-            const float ly = logf(cc);
-            const float lx = logf(1.0f - cc);
-            const float p = expf((o == 0 ? eps : S[c]) + ly);  // "unity" is eps (drc.py:58-59)
+            const float p = (o == 0 ? e_eps : Tr[c]) * cc;
             pv[c] = p;
-            pj[c] += p;
-            dp[c] += p * psi;
-            S[c] += lx;
-            Sd[c] += (double)lx;
+            Ps[c] += (double)p;
+            Qs[c] += (double)(p * psi);
+            Tr[c] *= 1.0f - cc;
           }
           if (probs) store_cx<CX>(probs + ((size_t)o * B + b) * ncol + ocol, pv);
         }
       }
     }
 #pragma unroll
-    for (int u = 0; u < PF; ++u)
+    for (int u = 0; u < G; ++u)
 #pragma unroll
       for (int c = 0; c < CX; ++c) cur[u][c] = nxt[u][c];
   }
-  float pl[CX];
+  float pl[CX], pj[CX], dp[CX];
 #pragma unroll
   for (int c = 0; c < CX; ++c) {
-    pl[c] = expf(S[c] + eps);
-    dp[c] += pl[c] * P.max_depth;
+    pl[c] = Tr[c] * e_eps;
+    Qs[c] += (double)(pl[c] * P.max_depth);
+    pj[c] = (float)Ps[c];
+    dp[c] = (float)Qs[c];
   }
   if (probs) store_cx<CX>(probs + ((size_t)Dz * B + b) * ncol + ocol, pl);
   if (proj) store_cx<CX>(proj + (size_t)b * ncol + ocol, pj);
   if (depth) store_cx<CX>(depth + (size_t)b * ncol + ocol, dp);
-  if (logt) {
+  if (sums) {
 #pragma unroll
-    for (int c = 0; c < CX; ++c) logt[(size_t)b * ncol + col + c] = Sd[c];
+    for (int c = 0; c < CX; ++c) {
+      sums[((size_t)b * ncol + col + c) * 2 + 0] = Ps[c];
+      sums[((size_t)b * ncol + col + c) * 2 + 1] = Qs[c];
+    }
   }
 }
 
-// Backward: walks each ray from far to near.  With gamma_i = dL/dp_i,
-// a_i = gamma_i p_i:  dL/dc_j = a_j/c_j - (sum_{i>j} a_i)/(1-c_j), masked by
-// eps <= G3_j <= 1-eps; then the scale/clip mask, dscale, and the z-FIR
-// adjoint.  S_j = logT - sum_{i>=j} log(1-c_i) is formed in fp64 so that no
-// precision is lost to the subtraction.  logt == null => an ascending
-// pre-pass recomputes it.
+// Backward, same walking direction as forward (so T_j and p_j are reproduced
+// bit for bit).  With gamma_i = dL/dp_i and a_i = gamma_i p_i:
+//   dL/dc_j = gamma_j Tq_j - (sum_{i>j} a_i) / (1 - c_j),   Tq_0 = e^eps, Tq_j = T_j,
+// masked by eps <= G3_j <= 1-eps; then the scale/clip mask, dscale, and the z-FIR
+// adjoint.  sum_{i>j} a_i = total - sum_{i<=j} a_i with both sums in float64, the
+// total coming from forward's saved (P,Q) when gamma_i = g + gd psi_i; a general
+// gamma (dprobs != null) or sums == null adds an ascending pre-pass for the total.
 template <int KC, int CX>
 __global__ void __launch_bounds__(DPC_BLOCK)
 k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ taps,
-       const float* __restrict__ scale, const double* __restrict__ logt,
+       const float* __restrict__ scale, const double* __restrict__ sums,
        const float* __restrict__ dproj, const float* __restrict__ ddepth,
        const float* __restrict__ dprobs, float* __restrict__ dgz, float* __restrict__ dscale, int B,
        int Dz, int D, int flip_h) {
@@ -995,58 +999,70 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
     const int y = col / D, x0 = col - y * D;
     const int ocol = (flip_h ? (D - 1 - y) : y) * D + x0;
     constexpr int h = KC / 2;
+    constexpr int G = zgroup(KC);
     const float eps = P.eps, one_m = 1.0f - P.eps;
+    const float e_eps = expf(eps);
     const bool has_s = scale != nullptr;
     const float s = has_s ? scale[b] : 1.0f;
     const float fDz = (float)Dz;
-    float g[CX], gd[CX], suffix[CX];
-    double St[CX], R[CX];
+    float g[CX], gd[CX], Tr[CX];
+    double tot[CX], A[CX];
 #pragma unroll
     for (int c = 0; c < CX; ++c) {
       g[c] = dproj ? dproj[(size_t)b * ncol + ocol + c] : 0.f;
       gd[c] = ddepth ? ddepth[(size_t)b * ncol + ocol + c] : 0.f;
-      R[c] = 0.0;
+      A[c] = 0.0;
+      Tr[c] = 1.0f;
     }
-    if (logt) {
+    if (sums && !dprobs) {
 #pragma unroll
-      for (int c = 0; c < CX; ++c) St[c] = logt[(size_t)b * ncol + col + c];
+      for (int c = 0; c < CX; ++c)
+        tot[c] = (double)g[c] * sums[((size_t)b * ncol + col + c) * 2 + 0] +
+                 (double)gd[c] * sums[((size_t)b * ncol + col + c) * 2 + 1];
     } else {
+      float Tp[CX];
 #pragma unroll
-      for (int c = 0; c < CX; ++c) St[c] = 0.0;
+      for (int c = 0; c < CX; ++c) {
+        tot[c] = 0.0;
+        Tp[c] = 1.0f;
+      }
       for (int j = 0; j < Dz; ++j) {
         float v[CX];
         load_cx<CX>(g2_in + base + (size_t)j * ncol, v);
+        const float psi = (float)j / fDz - 0.5f + P.camera_distance;
 #pragma unroll
         for (int c = 0; c < CX; ++c) {
           const float g3 = has_s ? clampf(v[c] * s, 0.f, 1.f) : v[c];
           const float cc = clampf(g3, eps, one_m);
-          St[c] += (double)logf(1.0f - cc);
+          const float p = (j == 0 ? e_eps : Tp[c]) * cc;
+          float gam = g[c] + gd[c] * psi;
+          if (dprobs) gam += dprobs[((size_t)j * B + b) * ncol + ocol + c];
+          tot[c] += (double)(gam * p);
+          Tp[c] *= 1.0f - cc;
         }
       }
-    }
 #pragma unroll
-    for (int c = 0; c < CX; ++c) {
-      float gl = gd[c] * P.max_depth;
-      if (dprobs) gl += dprobs[((size_t)Dz * B + b) * ncol + ocol + c];
-      suffix[c] = gl * expf((float)St[c] + eps);  // a_Dz
+      for (int c = 0; c < CX; ++c) {
+        float gl = gd[c] * P.max_depth;
+        if (dprobs) gl += dprobs[((size_t)Dz * B + b) * ncol + ocol + c];
+        tot[c] += (double)(gl * (Tp[c] * e_eps));
+      }
     }
     ZFir<KC, CX> fir;
     fir.init(taps);
-    constexpr int PF = DPC_Z_PF;
     const int T = Dz + h;
-    float cur[PF][CX], nxt[PF][CX];
+    float cur[G][CX], nxt[G][CX];
 #pragma unroll
-    for (int u = 0; u < PF; ++u) zload<CX>(g2_in + base, ncol, Dz - 1 - u, Dz, cur[u]);
-    for (int t0 = 0; t0 < T; t0 += PF) {
+    for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, u, Dz, cur[u]);
+    for (int t0 = 0; t0 < T; t0 += G) {
 #pragma unroll
-      for (int u = 0; u < PF; ++u) zload<CX>(g2_in + base, ncol, Dz - 1 - (t0 + PF + u), Dz, nxt[u]);
+      for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, t0 + G + u, Dz, nxt[u]);
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int t = t0 + u;
-        if (t < T) {
-          const int j = Dz - 1 - t;
+      for (int u = 0; u < G; ++u) {
+        const int j = t0 + u;
+        if (j < T) {
           float dg2[CX], o[CX];
-          if (j >= 0) {
+          if (j < Dz) {
             const float psi = (float)j / fDz - 0.5f + P.camera_distance;
 #pragma unroll
             for (int c = 0; c < CX; ++c) {
@@ -1054,18 +1070,16 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
               const float sg = vv * s;
               const float g3 = has_s ? clampf(sg, 0.f, 1.f) : vv;
               const float cc = clampf(g3, eps, one_m);
-              const float ly = logf(cc);
               const float omc = 1.0f - cc;
-              const float lx = logf(omc);
-              R[c] += (double)lx;
-              const float Sj = (float)(St[c] - R[c]);
-              const float p = expf((j == 0 ? eps : Sj) + ly);
+              const float Tq = (j == 0) ? e_eps : Tr[c];
               float gam = g[c] + gd[c] * psi;
               if (dprobs) gam += dprobs[((size_t)j * B + b) * ncol + ocol + c];
-              const float a = gam * p;
-              const float dc = a / cc - suffix[c] / omc;
+              const float gT = gam * Tq;                 // = a_j / c_j
+              A[c] += (double)(gT * cc);                  // a_j = gamma_j p_j
+              const float suffix = (float)(tot[c] - A[c]);
+              const float dc = gT - __fdividef(suffix, omc);
               const float dg3 = (g3 >= eps && g3 <= one_m) ? dc : 0.f;
-              suffix[c] += a;
+              Tr[c] *= omc;
               if (has_s) {
                 const bool m2 = (sg >= 0.f) && (sg <= 1.f);
                 dg2[c] = m2 ? s * dg3 : 0.f;
@@ -1078,12 +1092,12 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
 #pragma unroll
             for (int c = 0; c < CX; ++c) dg2[c] = 0.f;
           }
-          fir.push(dg2, o, true);
-          if (t >= h) store_cx<CX>(dgz + base + (size_t)(j + h) * ncol, o);
+          fir.push(dg2, o, u);
+          if (j >= h) store_cx<CX>(dgz + base + (size_t)(j - h) * ncol, o);
         }
       }
 #pragma unroll
-      for (int u = 0; u < PF; ++u)
+      for (int u = 0; u < G; ++u)
 #pragma unroll
         for (int c = 0; c < CX; ++c) cur[u][c] = nxt[u][c];
     }
@@ -1276,37 +1290,45 @@ int launch_blur_plane(hipStream_t st, const DpcShape& S, const float* in, float*
   return last_error();
 }
 
-inline int pick_cx(int D) { return ((D * D) % 2 == 0 && D % 2 == 0) ? 2 : 1; }
+#ifndef DPC_CX_PREF
+#define DPC_CX_PREF 2
+#endif
+inline int pick_cx(int D) {
+  if (DPC_CX_PREF >= 4 && D % 4 == 0) return 4;
+  if (DPC_CX_PREF >= 2 && D % 2 == 0) return 2;
+  return 1;
+}
 inline dim3 col_grid(const DpcShape& S, int cx) {
   const int nthr = (S.D * S.D + cx - 1) / cx;
   return dim3((nthr + DPC_BLOCK - 1) / DPC_BLOCK, S.B, 1);
 }
 inline bool z_fixed(int K) { return K == 0 || K == 3 || K == 5 || K == 7 || K == 9 || K == 11 || K == 21; }
 
-#define DPC_Z_DISPATCH(K, CX, MACRO) \
-  do {                               \
-    const int k_ = (K) == 0 ? 1 : (K); \
-    if (CX == 2) {                   \
-      switch (k_) {                  \
-        case 1: MACRO(1, 2); break;  \
-        case 3: MACRO(3, 2); break;  \
-        case 5: MACRO(5, 2); break;  \
-        case 7: MACRO(7, 2); break;  \
-        case 9: MACRO(9, 2); break;  \
-        case 11: MACRO(11, 2); break; \
-        case 21: MACRO(21, 2); break; \
-      }                              \
-    } else {                         \
-      switch (k_) {                  \
-        case 1: MACRO(1, 1); break;  \
-        case 3: MACRO(3, 1); break;  \
-        case 5: MACRO(5, 1); break;  \
-        case 7: MACRO(7, 1); break;  \
-        case 9: MACRO(9, 1); break;  \
-        case 11: MACRO(11, 1); break; \
-        case 21: MACRO(21, 1); break; \
-      }                              \
-    }                                \
+#define DPC_Z_CASES(CXV, MACRO)   \
+  switch (k_) {                    \
+    case 1: MACRO(1, CXV); break;  \
+    case 3: MACRO(3, CXV); break;  \
+    case 5: MACRO(5, CXV); break;  \
+    case 7: MACRO(7, CXV); break;  \
+    case 9: MACRO(9, CXV); break;  \
+    case 11: MACRO(11, CXV); break; \
+    case 21: MACRO(21, CXV); break; \
+  }
+#if DPC_CX_PREF >= 4
+#define DPC_Z_CASES4(MACRO) DPC_Z_CASES(4, MACRO)
+#else
+#define DPC_Z_CASES4(MACRO)
+#endif
+#define DPC_Z_DISPATCH(K, CX, MACRO)      \
+  do {                                    \
+    const int k_ = (K) == 0 ? 1 : (K);    \
+    if (CX == 4) {                        \
+      DPC_Z_CASES4(MACRO)                 \
+    } else if (CX == 2) {                 \
+      DPC_Z_CASES(2, MACRO)               \
+    } else {                              \
+      DPC_Z_CASES(1, MACRO)               \
+    }                                     \
   } while (0)
 
 int launch_blur_z(hipStream_t st, const DpcShape& S, const float* in, float* out, const float* tz, int Kz) {
@@ -1326,27 +1348,27 @@ int launch_blur_z(hipStream_t st, const DpcShape& S, const float* in, float* out
 // in -> (z-FIR Kz) -> collapse.  Kz must be z_fixed().
 int launch_zfwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const float* in, const float* tz,
                 int Kz, const float* scale, float* g2_out, float* probs, float* proj, float* depth,
-                double* logt, int clip_in, int flip_h) {
+                double* sums, int clip_in, int flip_h) {
   const dim3 block(DPC_BLOCK, 1, 1);
   const int cx = pick_cx(S.D);
   const dim3 grid = col_grid(S, cx);
 #define DPC_M(KC, CXV)                                                                                \
   DPC_LAUNCH("zfwd", (k_zfwd<KC, CXV>), grid, block, 0, st, P, in, (Kz > 0 ? tz : (const float*)nullptr), scale, \
-             g2_out, probs, proj, depth, logt, S.B, S.Dz, S.D, clip_in, flip_h)
+             g2_out, probs, proj, depth, sums, S.B, S.Dz, S.D, clip_in, flip_h)
   DPC_Z_DISPATCH(Kz, cx, DPC_M);
 #undef DPC_M
   return last_error();
 }
 
 int launch_zbwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const float* g2, const float* tz,
-                int Kz, const float* scale, const double* logt, const float* dproj, const float* ddepth,
+                int Kz, const float* scale, const double* sums, const float* dproj, const float* ddepth,
                 const float* dprobs, float* dgz, float* dscale, int flip_h) {
   const dim3 block(DPC_BLOCK, 1, 1);
   const int cx = pick_cx(S.D);
   const dim3 grid = col_grid(S, cx);
 #define DPC_M(KC, CXV)                                                                                \
   DPC_LAUNCH("zbwd", (k_zbwd<KC, CXV>), grid, block, 0, st, P, g2, (Kz > 0 ? tz : (const float*)nullptr), scale, \
-             logt, dproj, ddepth, dprobs, dgz, dscale, S.B, S.Dz, S.D, flip_h)
+             sums, dproj, ddepth, dprobs, dgz, dscale, S.B, S.Dz, S.D, flip_h)
   DPC_Z_DISPATCH(Kz, cx, DPC_M);
 #undef DPC_M
   return last_error();
@@ -1547,7 +1569,7 @@ int dpc_max_collapse_bwd(dpc_stream_t stream, const DpcShape* shape, const float
 int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* pc,
                         const float* pose, const float* trans, const float* scale, const float* focal,
                         const float* taps_x, const float* taps_y, const float* taps_z, float* tr_pc,
-                        float* grid_raw, float* grid_blur, double* ray_logt, float* proj, float* proj_depth,
+                        float* grid_raw, float* grid_blur, double* ray_sums, float* proj, float* proj_depth,
                         void* workspace, size_t workspace_bytes) {
   int rc = check_shape(shape, true);
   if (rc) return rc;
@@ -1558,7 +1580,7 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   if (!P.pose_is_quaternion && trans) return DPC_E_MODE;
   const bool drc = P.collapse_mode == DPC_COLLAPSE_DRC;
   if (!drc && P.collapse_mode != DPC_COLLAPSE_MAX) return DPC_E_MODE;
-  if (drc && !ray_logt) return DPC_E_NULL;
+  if (drc && !ray_sums) return DPC_E_NULL;
   const bool plane = S.Kx > 0 || S.Ky > 0;
   if (plane && (!workspace || workspace_bytes < dpc_workspace_bytes(shape, 0) ||
                 ((uintptr_t)workspace & 255) != 0))
@@ -1589,7 +1611,7 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   }
   // 3. z blur fused with the ray collapse
   if (drc && z_fixed(S.Kz))
-    return launch_zfwd(st, S, P, zin, taps_z, S.Kz, scale, grid_blur, nullptr, proj, proj_depth, ray_logt,
+    return launch_zfwd(st, S, P, zin, taps_z, S.Kz, scale, grid_blur, nullptr, proj, proj_depth, ray_sums,
                        clip_in, 1);
   // generic tap count or max-collapse: materialise G2, then collapse separately
   if (S.Kz > 0) {
@@ -1601,7 +1623,7 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   if (drc) {
     // G2 already in grid_blur (or still the unblurred grid): collapse with a K=1 pass
     return launch_zfwd(st, S, P, zin, nullptr, 0, scale, (zin == grid_blur ? nullptr : grid_blur), nullptr,
-                       proj, proj_depth, ray_logt, clip_in, 1);
+                       proj, proj_depth, ray_sums, clip_in, 1);
   }
   if (zin != grid_blur) {  // no z blur: G2 = (clipped) input; copy through the K=1 FIR kernel
     const int cx = pick_cx(S.D);
@@ -1618,7 +1640,7 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
 int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* pc,
                          const float* pose, const float* trans, const float* scale, const float* focal,
                          const float* taps_x, const float* taps_y, const float* taps_z, const float* tr_pc,
-                         const float* grid_raw, const float* grid_blur, const double* ray_logt,
+                         const float* grid_raw, const float* grid_blur, const double* ray_sums,
                          const float* dproj, const float* dproj_depth, const float* dtr_pc_in, float* dpc,
                          float* dpose, float* dtrans, float* dscale, float* dfocal, void* workspace,
                          size_t workspace_bytes) {
@@ -1647,13 +1669,13 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   }
   // 1. collapse VJP (+ z-FIR adjoint) -> tA
   if (drc && z_fixed(S.Kz)) {
-    rc = launch_zbwd(st, S, P, grid_blur, taps_z, S.Kz, scale, ray_logt, dproj, dproj_depth, nullptr, tA,
+    rc = launch_zbwd(st, S, P, grid_blur, taps_z, S.Kz, scale, ray_sums, dproj, dproj_depth, nullptr, tA,
                      dscale, 1);
     if (rc) return rc;
   } else {
     float* first = (S.Kz > 0) ? tB : tA;
     if (drc) {
-      rc = launch_zbwd(st, S, P, grid_blur, nullptr, 0, scale, ray_logt, dproj, dproj_depth, nullptr, first,
+      rc = launch_zbwd(st, S, P, grid_blur, nullptr, 0, scale, ray_sums, dproj, dproj_depth, nullptr, first,
                        dscale, 1);
     } else {
       DPC_LAUNCH("max_bwd", (k_max_bwd), col_grid(S, 1), dim3(DPC_BLOCK, 1, 1), 0, st, grid_blur, scale, dproj, first,

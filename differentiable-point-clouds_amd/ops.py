@@ -135,7 +135,7 @@ class ProjectFused(torch.autograd.Function):
         grid_raw = new(B, Dz, D, D)
         grid_blur = new(B, Dz, D, D)
         drc = meta.collapse_mode == _capi.DPC_COLLAPSE_DRC
-        logt = new(B, D, D, dtype=torch.float64) if drc else None
+        logt = new(B, D, D, 2, dtype=torch.float64) if drc else None
         proj = new(B, D, D, 1)
         depth = new(B, D, D, 1) if drc else None
         ws = _Workspace(lib, shape, 0, pc)

@@ -92,13 +92,14 @@ size_t dpc_workspace_bytes(const DpcShape* shape, int direction);
  *   -> drc_depth_projection (drc.py:146-153) -> flips (:270,273).
  * Saved for backward (caller-owned): tr_pc [B,N,3], grid_raw [B,Dz,D,D]
  * (pre-clip scatter), grid_blur [B,Dz,D,D] (post-blur, pre-scale),
- * ray_logt [B,D,D] float64 (total log-transmittance per ray, grid-row order).
+ * ray_sums [B,D,D,2] float64 (per ray, grid-row order: sum_{j<Dz} p_j and
+ * sum_{j<=Dz} p_j psi_j of the event probabilities, needed by the backward).
  * trans/scale/focal/taps/proj_depth nullable.  proj, proj_depth are H-flipped. */
 int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params,
                         const float* pc, const float* pose, const float* trans /*[B,3]|null*/,
                         const float* scale /*[B]|null*/, const float* focal /*[B]|null*/,
                         const float* taps_x, const float* taps_y, const float* taps_z,
-                        float* tr_pc, float* grid_raw, float* grid_blur, double* ray_logt,
+                        float* tr_pc, float* grid_raw, float* grid_blur, double* ray_sums,
                         float* proj, float* proj_depth /*null for MAX*/,
                         void* workspace, size_t workspace_bytes);
 
@@ -113,7 +114,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
                          const float* scale, const float* focal,
                          const float* taps_x, const float* taps_y, const float* taps_z,
                          const float* tr_pc, const float* grid_raw, const float* grid_blur,
-                         const double* ray_logt,
+                         const double* ray_sums,
                          const float* dproj, const float* dproj_depth, const float* dtr_pc_in,
                          float* dpc, float* dpose, float* dtrans, float* dscale, float* dfocal,
                          void* workspace, size_t workspace_bytes);

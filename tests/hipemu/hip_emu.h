@@ -119,6 +119,7 @@ static inline float __shfl_xor(float v, int mask, int width = 64) {
   return r;
 }
 
+static inline float __fdividef(float a, float b) { return a / b; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
   memset(p, v, n);
   return hipSuccess;
