@@ -355,10 +355,12 @@ __device__ __forceinline__ void scatter_point(float* __restrict__ grid, int b, i
 
 // Trilinear gather VJP.  dgrid is either d(G0) itself (Kx == 0, mask == null)
 // or the (z,y)-blurred gradient, in which case the x-blur (taps_x, Kx) is
-// evaluated here, only at the <= 8 touched cells, and `mask` (= G0) applies
-// the clip_by_value(.,0,1) gradient mask of point_cloud.py:240.
+// evaluated here, only at the <= 8 touched cells, and `mask` (= G0, dense) or
+// `cmask` (per-point corner bits) applies the clip_by_value(.,0,1) gradient
+// mask of point_cloud.py:240.
 __device__ __forceinline__ void gather_point(const float* __restrict__ dgrid,
                                              const float* __restrict__ mask,
+                                             const unsigned char* __restrict__ cmask /*4 bytes of this point*/,
                                              const float* __restrict__ taps_x, int Kx, int b, int Dz,
                                              int D, float w, float v, float u, float& dw, float& dv,
                                              float& du) {
@@ -397,7 +399,9 @@ __device__ __forceinline__ void gather_point(const float* __restrict__ dgrid,
         const int xx = c.ix + l;
         if (xx >= D) continue;
         float gg = g[l];
-        if (mask) {
+        if (cmask) {  // bit l of byte (k,j): 0 <= G0 <= 1 at that corner (written by k_splat_xy)
+          gg = ((cmask[k * 2 + j] >> l) & 1) ? gg : 0.f;
+        } else if (mask) {
           const float m0 = mask[row + xx];
           gg = (m0 >= 0.f && m0 <= 1.f) ? gg : 0.f;
         }
@@ -452,7 +456,7 @@ k_gather(DpcShape S, const float* __restrict__ tr_pc, const float* __restrict__ 
   if (n >= S.N) return;
   const size_t o = ((size_t)b * S.N + n) * 3;
   float dw, dv, du;
-  gather_point(dgrid, nullptr, nullptr, 0, b, S.Dz, S.D, tr_pc[o], tr_pc[o + 1], tr_pc[o + 2], dw, dv, du);
+  gather_point(dgrid, nullptr, nullptr, nullptr, 0, b, S.Dz, S.D, tr_pc[o], tr_pc[o + 1], tr_pc[o + 2], dw, dv, du);
   dtr_pc[o] = dw;
   dtr_pc[o + 1] = dv;
   dtr_pc[o + 2] = du;
@@ -465,9 +469,9 @@ __global__ void __launch_bounds__(DPC_BLOCK)
 k_points_bwd(DpcShape S, DpcParams P, const float* __restrict__ pc, const float* __restrict__ pose,
              const float* __restrict__ trans, const float* __restrict__ focal,
              const float* __restrict__ tr_pc, const float* __restrict__ dgrid,
-             const float* __restrict__ mask, const float* __restrict__ taps_x,
-             const float* __restrict__ dtr_in /*nullable when GATHER*/, float* __restrict__ dpc,
-             float* __restrict__ accum /*[B,16], zeroed*/) {
+             const float* __restrict__ mask, const unsigned char* __restrict__ cmask,
+             const float* __restrict__ taps_x, const float* __restrict__ dtr_in /*nullable when GATHER*/,
+             float* __restrict__ dpc, float* __restrict__ accum /*[B,16], zeroed*/) {
   const int b = blockIdx.x;  // view-major block ids: b + B*chunk => one XCD (L2) per view when B % 8 == 0
   const int n = blockIdx.y * blockDim.x + threadIdx.x;
   float acc[16];
@@ -479,7 +483,8 @@ k_points_bwd(DpcShape S, DpcParams P, const float* __restrict__ pc, const float*
     const size_t o = ((size_t)b * S.N + n) * 3;
     float dw = 0.f, dv = 0.f, du = 0.f;
     if (GATHER)
-      gather_point(dgrid, mask, taps_x, S.Kx, b, S.Dz, S.D, tr_pc[o], tr_pc[o + 1], tr_pc[o + 2], dw, dv, du);
+      gather_point(dgrid, mask, cmask ? cmask + ((size_t)b * S.N + n) * 4 : nullptr, taps_x, S.Kx, b, S.Dz, S.D,
+                   tr_pc[o], tr_pc[o + 1], tr_pc[o + 2], dw, dv, du);
     if (dtr_in) {
       dw += dtr_in[o];
       dv += dtr_in[o + 1];
@@ -501,10 +506,12 @@ k_points_bwd(DpcShape S, DpcParams P, const float* __restrict__ pc, const float*
 template <bool QUAT>
 __global__ void k_pose_finalize(DpcShape S, DpcParams P, const float* __restrict__ pose,
                                 const float* __restrict__ accum, float* __restrict__ dpose,
-                                float* __restrict__ dtrans, float* __restrict__ dfocal) {
+                                float* __restrict__ dtrans, float* __restrict__ dfocal,
+                                float* __restrict__ dscale /*nullable: from accumulator slot 15*/) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= S.B) return;
   const float* a = accum + 16 * b;
+  if (dscale) dscale[b] = a[15];
   if (QUAT) {
     const float* q = pose + 4 * b;
     const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
@@ -796,6 +803,183 @@ k_blur_xy_stream(const float* __restrict__ in, float* __restrict__ out, const fl
     for (int u = 0; u < G; ++u)
 #pragma unroll
       for (int c = 0; c < 4; ++c) cur[u][c] = nxt[u][c];
+  }
+}
+
+// ===========================================================================
+// fused forward front end: z-bucketed points -> per-plane LDS splat -> clip ->
+// x,y blur -> xy-blurred plane.  Replaces {zero-fill G0, global float atomics,
+// read G0 back} of the generic path: the raw grid G0 never exists in HBM.  The
+// clip_by_value(G0,0,1) gradient mask that backward needs is kept as one bit
+// per touched corner (cmask [B,N,4] bytes: byte k*2+j, bit l).
+// ===========================================================================
+
+// counting sort of one view's points by depth cell iz (bin Dz = dropped points)
+__global__ void __launch_bounds__(1024)
+k_zsort(DpcShape S, const float* __restrict__ tr_pc, int* __restrict__ order, int* __restrict__ zstart) {
+  DPC_DYN_SMEM(int, hist);  // [Dz + 2]
+  const int b = blockIdx.x;
+  const int N = S.N, Dz = S.Dz, D = S.D;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  for (int i = tid; i < Dz + 2; i += nth) hist[i] = 0;
+  __syncthreads();
+  const float* tp = tr_pc + (size_t)b * N * 3;
+  for (int n = tid; n < N; n += nth) {
+    const Cell c = locate(tp[3 * n], tp[3 * n + 1], tp[3 * n + 2], Dz, D);
+    atomicAdd(&hist[c.valid ? c.iz : Dz], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i <= Dz; ++i) {
+      const int cnt = hist[i];
+      hist[i] = run;
+      run += cnt;
+    }
+    hist[Dz + 1] = run;
+  }
+  __syncthreads();
+  for (int i = tid; i < Dz + 2; i += nth) zstart[(size_t)b * (Dz + 2) + i] = hist[i];
+  __syncthreads();
+  for (int n = tid; n < N; n += nth) {
+    const Cell c = locate(tp[3 * n], tp[3 * n + 1], tp[3 * n + 2], Dz, D);
+    const int slot = atomicAdd(&hist[c.valid ? c.iz : Dz], 1);
+    order[(size_t)b * N + slot] = n;
+  }
+}
+
+// WG = (view b, plane z, y-strip).  LDS tile = rows [y0-h, y0+SH+h) x D.
+template <int KC>
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ order,
+           const int* __restrict__ zstart, const float* __restrict__ taps_x,
+           const float* __restrict__ taps_y, float* __restrict__ out, unsigned char* __restrict__ cmask,
+           int SH, int nstrips, int lr_shift) {
+  DPC_DYN_SMEM(float, tile);
+  constexpr int h = KC / 2;
+  constexpr int G = zgroup(KC);
+  const int D = S.D, Dz = S.Dz, N = S.N;
+  const int bid = blockIdx.x;
+  const int strip = bid % nstrips;
+  const int pz = bid / nstrips;
+  const int z = pz % Dz, b = pz / Dz;
+  const int y0 = strip * SH;
+  const int RT = SH + 2 * h;
+  const int tid = threadIdx.x, nth = blockDim.x;
+
+  // 1. zero the tile
+  for (int i = tid * 4; i < RT * D; i += nth * 4)
+    *reinterpret_cast<float4*>(tile + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+
+  // 2. splat the points of depth cells z-1 (upper corner, k=1) and z (k=0)
+  const int* zs = zstart + (size_t)b * (Dz + 2);
+  const int lo = zs[z > 0 ? z - 1 : 0], mid = zs[z], hi = zs[z + 1];
+  const float* tp = tr_pc + (size_t)b * N * 3;
+  for (int i = lo + tid; i < hi; i += nth) {
+    const int n = order[(size_t)b * N + i];
+    const int k = (i < mid) ? 1 : 0;
+    const Cell c = locate(tp[3 * n], tp[3 * n + 1], tp[3 * n + 2], Dz, D);
+    const float wz = k ? c.rz : (1.0f - c.rz);
+    const float wy[2] = {1.0f - c.ry, c.ry};
+    const float wx[2] = {1.0f - c.rx, c.rx};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int yy = c.iy + j;
+      const int t = yy - (y0 - h);
+      if (yy >= D || t < 0 || t >= RT) continue;
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const int xx = c.ix + l;
+        if (xx < D) atomicAdd(&tile[t * D + xx], wz * wy[j] * wx[l]);
+      }
+    }
+  }
+  __syncthreads();
+
+  // 3. clip-gradient bits of the corners this strip owns
+  for (int i = lo + tid; i < hi; i += nth) {
+    const int n = order[(size_t)b * N + i];
+    const int k = (i < mid) ? 1 : 0;
+    const Cell c = locate(tp[3 * n], tp[3 * n + 1], tp[3 * n + 2], Dz, D);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int yy = c.iy + j;
+      if (yy >= D || yy < y0 || yy >= y0 + SH) continue;
+      const int t = yy - (y0 - h);
+      unsigned bits = 0;
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const int xx = c.ix + l;
+        if (xx < D) {
+          const float g0 = tile[t * D + xx];
+          bits |= (g0 >= 0.f && g0 <= 1.f) ? (1u << l) : 0u;
+        }
+      }
+      cmask[((size_t)b * N + n) * 4 + k * 2 + j] = (unsigned char)bits;
+    }
+  }
+  __syncthreads();
+
+  // 4. clip + x-blur, rows in place (halo from neighbour lanes, as in k_blur_xy_stream)
+  const int lane = tid & 63, wave = tid >> 6;
+  const int LR = 1 << lr_shift;
+  const int PL = 64 >> lr_shift;
+  const int lx = lane & (LR - 1);
+  const int stream = wave * PL + (lane >> lr_shift);
+  const int nstream = (nth >> 6) * PL;
+  float tpx[KC];
+#pragma unroll
+  for (int m = 0; m < KC; ++m) tpx[m] = taps_x[m];
+  for (int t0 = 0; t0 < RT; t0 += nstream) {
+    const int t = t0 + stream;
+    const bool rowok = t < RT;
+    float v[4], xb[4];
+    load_cx<4>(tile + (rowok ? t : 0) * D + lx * 4, v);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = rowok ? clampf(v[c], 0.f, 1.f) : 0.f;
+    float w[4 + 2 * h];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[h + c] = v[c];
+#pragma unroll
+    for (int e = 1; e <= h; ++e) {
+      const int dl = (e + 3) / 4;
+      const int jl = (4 * dl - e) & 3;
+      const float vl = __shfl(v[jl], (lane - dl) & 63, 64);
+      w[h - e] = (lx - dl >= 0) ? vl : 0.f;
+      const int jr = (e - 1) & 3;
+      const float vr = __shfl(v[jr], (lane + dl) & 63, 64);
+      w[h + 3 + e] = (lx + dl < LR) ? vr : 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float a = 0.f;
+#pragma unroll
+      for (int m = 0; m < KC; ++m) a += tpx[m] * w[o + m];
+      xb[o] = a;
+    }
+    if (rowok) store_cx<4>(tile + t * D + lx * 4, xb);
+  }
+  __syncthreads();
+
+  // 5. y-blur: each stream produces RS output rows, register FIR over RS + 2h tile rows
+  const int RS = SH / nstream;
+  ZFir<KC, 4> fir;
+  fir.init(taps_y);
+  const int steps = RS + 2 * h;
+  float* oplane = out + (size_t)pz * D * D;
+  for (int q0 = 0; q0 < steps; q0 += G) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int q = q0 + u;
+      if (q < steps) {
+        float v[4], o[4];
+        load_cx<4>(tile + (stream * RS + q) * D + lx * 4, v);
+        fir.push(v, o, u);
+        const int gy = y0 + stream * RS + q - 2 * h;
+        if (q >= 2 * h && gy < D) store_cx<4>(oplane + (size_t)gy * D + lx * 4, o);
+      }
+    }
   }
 }
 
@@ -1104,7 +1288,7 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
   }
   if (dscale) {  // uniform across the grid
     block_reduce_sum<1>(dsacc);
-    if (threadIdx.x == 0) atomicAdd(dscale + b, dsacc[0]);
+    if (threadIdx.x == 0) atomicAdd(dscale + 16 * (size_t)b + 15, dsacc[0]);  // [B,16] accumulator, slot 15
   }
 }
 
@@ -1167,7 +1351,7 @@ k_max_bwd(const float* __restrict__ vox, const float* __restrict__ scale,
   }
   if (dscale) {
     block_reduce_sum<1>(dsacc);
-    if (threadIdx.x == 0) atomicAdd(dscale + b, dsacc[0]);
+    if (threadIdx.x == 0) atomicAdd(dscale + 16 * (size_t)b + 15, dsacc[0]);  // [B,16] accumulator, slot 15
   }
 }
 
@@ -1376,15 +1560,18 @@ int launch_zbwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const flo
 
 int launch_points_bwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const float* pc,
                       const float* pose, const float* trans, const float* focal, const float* tr_pc,
-                      const float* dgrid, const float* mask, const float* taps_x, const float* dtr_in,
-                      bool gather, float* dpc, float* dpose, float* dtrans, float* dfocal, float* accum) {
-  hipError_t e = dpc_memset("memset_small", accum, sizeof(float) * 16 * (size_t)S.B, st);
-  if (e != hipSuccess) return (int)e;
+                      const float* dgrid, const float* mask, const unsigned char* cmask, const float* taps_x,
+                      const float* dtr_in, bool gather, float* dpc, float* dpose, float* dtrans, float* dfocal,
+                      float* dscale, float* accum, bool zero_accum) {
+  if (zero_accum) {
+    hipError_t e = dpc_memset("memset_small", accum, sizeof(float) * 16 * (size_t)S.B, st);
+    if (e != hipSuccess) return (int)e;
+  }
   const dim3 grid = point_grid(S), block(DPC_BLOCK, 1, 1);
   const bool quat = P.pose_is_quaternion != 0;
 #define DPC_PB(Q, G)                                                                                  \
   DPC_LAUNCH("points_bwd", (k_points_bwd<Q, G>), grid, block, 0, st, S, P, pc, pose, trans, focal, tr_pc, dgrid, mask, \
-             taps_x, dtr_in, dpc, accum)
+             cmask, taps_x, dtr_in, dpc, accum)
   if (quat && gather) DPC_PB(true, true);
   else if (quat) DPC_PB(true, false);
   else if (gather) DPC_PB(false, true);
@@ -1392,9 +1579,58 @@ int launch_points_bwd(hipStream_t st, const DpcShape& S, const DpcParams& P, con
 #undef DPC_PB
   const dim3 fg((S.B + 63) / 64, 1, 1), fb(64, 1, 1);
   if (quat)
-    DPC_LAUNCH("pose_finalize", (k_pose_finalize<true>), fg, fb, 0, st, S, P, pose, accum, dpose, dtrans, dfocal);
+    DPC_LAUNCH("pose_finalize", (k_pose_finalize<true>), fg, fb, 0, st, S, P, pose, accum, dpose, dtrans, dfocal,
+               dscale);
   else
-    DPC_LAUNCH("pose_finalize", (k_pose_finalize<false>), fg, fb, 0, st, S, P, pose, accum, dpose, dtrans, dfocal);
+    DPC_LAUNCH("pose_finalize", (k_pose_finalize<false>), fg, fb, 0, st, S, P, pose, accum, dpose, dtrans, dfocal,
+               dscale);
+  return last_error();
+}
+
+// ---- fused front end (k_zsort + k_splat_xy) -------------------------------------
+struct SplatPlan {
+  bool ok;
+  int SH, nstrips, lr_shift;
+  size_t lds_bytes;
+};
+SplatPlan splat_plan(const DpcShape& S) {
+  SplatPlan p = {false, 0, 0, 0, 0};
+  const int D = S.D, K = S.Kx;
+  if (S.Kx != S.Ky || (K != 5 && K != 11 && K != 21)) return p;
+  if (D < 32 || D > 256 || (D & (D - 1)) != 0 || S.N <= 0) return p;
+  int lr_shift = 0;
+  while ((4 << lr_shift) < D) ++lr_shift;
+  const int nstream = (DPC_BLOCK / 64) * (64 >> lr_shift);
+  int SH = D;
+  while (SH >= nstream && sizeof(float) * (size_t)(SH + 2 * (K / 2)) * D > 48 * 1024) SH >>= 1;
+  if (SH < nstream || SH % nstream != 0) return p;
+  p.ok = true;
+  p.SH = SH;
+  p.nstrips = D / SH;
+  p.lr_shift = lr_shift;
+  p.lds_bytes = sizeof(float) * (size_t)(SH + 2 * (K / 2)) * D;
+  return p;
+}
+inline size_t splat_index_bytes(const DpcShape& S) {
+  return align256(sizeof(int) * (size_t)S.B * S.N) + align256(sizeof(int) * (size_t)S.B * (S.Dz + 2));
+}
+
+int launch_splat_xy(hipStream_t st, const DpcShape& S, const SplatPlan& pl, const float* tr_pc, int* order,
+                    int* zstart, const float* tx, const float* ty, float* out, unsigned char* cmask) {
+  int zt = 64;
+  while (zt < 1024 && zt < S.N) zt <<= 1;
+  DPC_LAUNCH("zsort", (k_zsort), dim3(S.B, 1, 1), dim3(zt, 1, 1), sizeof(int) * (size_t)(S.Dz + 2), st, S, tr_pc,
+             order, zstart);
+  const long long nblk = (long long)S.B * S.Dz * pl.nstrips;
+  if (nblk > 0x7fffffffLL) return DPC_E_SHAPE;
+  const dim3 grid((unsigned)nblk, 1, 1), block(DPC_BLOCK, 1, 1);
+#define DPC_SP(KC)                                                                                         \
+  DPC_LAUNCH("splat_xy", (k_splat_xy<KC>), grid, block, pl.lds_bytes, st, S, tr_pc, (const int*)order,    \
+             (const int*)zstart, tx, ty, out, cmask, pl.SH, pl.nstrips, pl.lr_shift)
+  if (S.Kx == 5) DPC_SP(5);
+  else if (S.Kx == 11) DPC_SP(11);
+  else DPC_SP(21);
+#undef DPC_SP
   return last_error();
 }
 
@@ -1409,6 +1645,11 @@ int dpc_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(dpcprof::g_mu);
   dpcprof::g_on = on != 0;
   return DPC_OK;
+}
+
+int dpc_saved_layout(const DpcShape* shape, const DpcParams* params) {
+  if (check_shape(shape, true) != DPC_OK || !params) return DPC_E_SHAPE;
+  return splat_plan(*shape).ok ? 2 : 1;  // bit 0: grid_raw, bit 1: clip_mask
 }
 
 int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, int width) {
@@ -1451,7 +1692,7 @@ size_t dpc_workspace_bytes(const DpcShape* shape, int direction) {
   if (check_shape(shape, false) != DPC_OK) return 0;
   const size_t g = align256(grid_elems(*shape) * sizeof(float));
   const size_t acc = align256(sizeof(float) * 16 * (size_t)shape->B);
-  return direction == 0 ? g : 2 * g + acc;
+  return direction == 0 ? g + splat_index_bytes(*shape) : 2 * g + acc;
 }
 
 int dpc_transform_fwd(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* pc,
@@ -1479,7 +1720,7 @@ int dpc_transform_bwd(dpc_stream_t stream, const DpcShape* shape, const DpcParam
   if (!params || !pc || !pose || !dtr_pc || !dpc || !dpose || !scratch) return DPC_E_NULL;
   if (!params->pose_is_quaternion && trans) return DPC_E_MODE;
   return launch_points_bwd((hipStream_t)stream, *shape, *params, pc, pose, trans, focal, nullptr, nullptr,
-                           nullptr, nullptr, dtr_pc, false, dpc, dpose, dtrans, dfocal, scratch);
+                           nullptr, nullptr, nullptr, dtr_pc, false, dpc, dpose, dtrans, dfocal, nullptr, scratch, true);
 }
 
 int dpc_voxelize_fwd(dpc_stream_t stream, const DpcShape* shape, const float* tr_pc, float* grid) {
@@ -1569,11 +1810,11 @@ int dpc_max_collapse_bwd(dpc_stream_t stream, const DpcShape* shape, const float
 int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* pc,
                         const float* pose, const float* trans, const float* scale, const float* focal,
                         const float* taps_x, const float* taps_y, const float* taps_z, float* tr_pc,
-                        float* grid_raw, float* grid_blur, double* ray_sums, float* proj, float* proj_depth,
-                        void* workspace, size_t workspace_bytes) {
+                        float* grid_raw, unsigned char* clip_mask, float* grid_blur, double* ray_sums,
+                        float* proj, float* proj_depth, void* workspace, size_t workspace_bytes) {
   int rc = check_shape(shape, true);
   if (rc) return rc;
-  if (!params || !pc || !pose || !tr_pc || !grid_raw || !grid_blur || !proj) return DPC_E_NULL;
+  if (!params || !pc || !pose || !tr_pc || !grid_blur || !proj) return DPC_E_NULL;
   const DpcShape& S = *shape;
   const DpcParams& P = *params;
   if ((S.Kx > 0 && !taps_x) || (S.Ky > 0 && !taps_y) || (S.Kz > 0 && !taps_z)) return DPC_E_NULL;
@@ -1581,33 +1822,54 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   const bool drc = P.collapse_mode == DPC_COLLAPSE_DRC;
   if (!drc && P.collapse_mode != DPC_COLLAPSE_MAX) return DPC_E_MODE;
   if (drc && !ray_sums) return DPC_E_NULL;
+  const SplatPlan plan = splat_plan(S);
+  if (plan.ok ? !clip_mask : !grid_raw) return DPC_E_NULL;
   const bool plane = S.Kx > 0 || S.Ky > 0;
   if (plane && (!workspace || workspace_bytes < dpc_workspace_bytes(shape, 0) ||
                 ((uintptr_t)workspace & 255) != 0))
     return DPC_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   float* tmp = (float*)workspace;
+  const dim3 pgrid = point_grid(S), pblock(DPC_BLOCK, 1, 1);
 
-  // 1. zero G0, transform + scatter
-  hipError_t e = dpc_memset("memset_grid", grid_raw, grid_elems(S) * sizeof(float), st);
-  if (e != hipSuccess) return (int)e;
-  {
-    const dim3 grid = point_grid(S), block(DPC_BLOCK, 1, 1);
+  const float* zin;
+  int clip_in;
+  if (plan.ok) {
+    // 1+2 fused front end: transform -> z-bucket -> per-plane LDS splat + clip + x,y blur
     if (P.pose_is_quaternion)
-      DPC_LAUNCH("points_fwd", (k_points_fwd<true>), grid, block, 0, st, S, P, pc, pose, trans, focal, tr_pc, grid_raw);
+      DPC_LAUNCH("points_fwd", (k_points_fwd<true>), pgrid, pblock, 0, st, S, P, pc, pose, trans, focal, tr_pc,
+                 (float*)nullptr);
     else
-      DPC_LAUNCH("points_fwd", (k_points_fwd<false>), grid, block, 0, st, S, P, pc, pose, trans, focal, tr_pc, grid_raw);
+      DPC_LAUNCH("points_fwd", (k_points_fwd<false>), pgrid, pblock, 0, st, S, P, pc, pose, trans, focal, tr_pc,
+                 (float*)nullptr);
     rc = last_error();
     if (rc) return rc;
-  }
-  // 2. clip + x,y blur (LDS tiles)
-  const float* zin = grid_raw;
-  int clip_in = 1;
-  if (plane) {
-    rc = launch_blur_plane(st, S, grid_raw, tmp, taps_x, taps_y, S.Kx, S.Ky, 1);
+    char* ws = (char*)workspace + align256(grid_elems(S) * sizeof(float));
+    int* order = (int*)ws;
+    int* zstart = (int*)(ws + align256(sizeof(int) * (size_t)S.B * S.N));
+    rc = launch_splat_xy(st, S, plan, tr_pc, order, zstart, taps_x, taps_y, tmp, clip_mask);
     if (rc) return rc;
     zin = tmp;
     clip_in = 0;
+  } else {
+    // 1. zero G0, transform + scatter (global float atomics)
+    hipError_t e = dpc_memset("memset_grid", grid_raw, grid_elems(S) * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    if (P.pose_is_quaternion)
+      DPC_LAUNCH("points_fwd", (k_points_fwd<true>), pgrid, pblock, 0, st, S, P, pc, pose, trans, focal, tr_pc, grid_raw);
+    else
+      DPC_LAUNCH("points_fwd", (k_points_fwd<false>), pgrid, pblock, 0, st, S, P, pc, pose, trans, focal, tr_pc, grid_raw);
+    rc = last_error();
+    if (rc) return rc;
+    // 2. clip + x,y blur
+    zin = grid_raw;
+    clip_in = 1;
+    if (plane) {
+      rc = launch_blur_plane(st, S, grid_raw, tmp, taps_x, taps_y, S.Kx, S.Ky, 1);
+      if (rc) return rc;
+      zin = tmp;
+      clip_in = 0;
+    }
   }
   // 3. z blur fused with the ray collapse
   if (drc && z_fixed(S.Kz))
@@ -1626,8 +1888,6 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
                        proj, proj_depth, ray_sums, clip_in, 1);
   }
   if (zin != grid_blur) {  // no z blur: G2 = (clipped) input; copy through the K=1 FIR kernel
-    const int cx = pick_cx(S.D);
-    (void)cx;
     rc = launch_zfwd(st, S, P, zin, nullptr, 0, nullptr, grid_blur, nullptr, nullptr, nullptr, nullptr,
                      clip_in, 1);
     if (rc) return rc;
@@ -1640,13 +1900,13 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
 int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* pc,
                          const float* pose, const float* trans, const float* scale, const float* focal,
                          const float* taps_x, const float* taps_y, const float* taps_z, const float* tr_pc,
-                         const float* grid_raw, const float* grid_blur, const double* ray_sums,
-                         const float* dproj, const float* dproj_depth, const float* dtr_pc_in, float* dpc,
-                         float* dpose, float* dtrans, float* dscale, float* dfocal, void* workspace,
-                         size_t workspace_bytes) {
+                         const float* grid_raw, const unsigned char* clip_mask, const float* grid_blur,
+                         const double* ray_sums, const float* dproj, const float* dproj_depth,
+                         const float* dtr_pc_in, float* dpc, float* dpose, float* dtrans, float* dscale,
+                         float* dfocal, void* workspace, size_t workspace_bytes) {
   int rc = check_shape(shape, true);
   if (rc) return rc;
-  if (!params || !pc || !pose || !tr_pc || !grid_raw || !grid_blur || !dpc || !dpose) return DPC_E_NULL;
+  if (!params || !pc || !pose || !tr_pc || !grid_blur || !dpc || !dpose) return DPC_E_NULL;
   const DpcShape& S = *shape;
   const DpcParams& P = *params;
   if ((S.Kx > 0 && !taps_x) || (S.Ky > 0 && !taps_y) || (S.Kz > 0 && !taps_z)) return DPC_E_NULL;
@@ -1655,31 +1915,32 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   if (!drc && P.collapse_mode != DPC_COLLAPSE_MAX) return DPC_E_MODE;
   if (!dproj && !(drc && dproj_depth)) return DPC_E_NULL;
   if (scale && !dscale) return DPC_E_NULL;
+  const bool use_cmask = splat_plan(S).ok;
+  if (use_cmask ? !clip_mask : !grid_raw) return DPC_E_NULL;
   if (!workspace || workspace_bytes < dpc_workspace_bytes(shape, 1) || ((uintptr_t)workspace & 255) != 0)
     return DPC_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const size_t gbytes = align256(grid_elems(S) * sizeof(float));
   float* tA = (float*)workspace;
   float* tB = (float*)((char*)workspace + gbytes);
-  float* accum = (float*)((char*)workspace + 2 * gbytes);
+  float* accum = (float*)((char*)workspace + 2 * gbytes);  // [B,16]: pose/trans/focal sums, slot 15 = dscale
 
-  if (dscale) {
-    hipError_t e = dpc_memset("memset_small", dscale, sizeof(float) * (size_t)S.B, st);
-    if (e != hipSuccess) return (int)e;
-  }
+  hipError_t e = dpc_memset("memset_small", accum, sizeof(float) * 16 * (size_t)S.B, st);
+  if (e != hipSuccess) return (int)e;
+  float* ds_acc = scale ? accum : nullptr;
   // 1. collapse VJP (+ z-FIR adjoint) -> tA
   if (drc && z_fixed(S.Kz)) {
     rc = launch_zbwd(st, S, P, grid_blur, taps_z, S.Kz, scale, ray_sums, dproj, dproj_depth, nullptr, tA,
-                     dscale, 1);
+                     ds_acc, 1);
     if (rc) return rc;
   } else {
     float* first = (S.Kz > 0) ? tB : tA;
     if (drc) {
       rc = launch_zbwd(st, S, P, grid_blur, nullptr, 0, scale, ray_sums, dproj, dproj_depth, nullptr, first,
-                       dscale, 1);
+                       ds_acc, 1);
     } else {
       DPC_LAUNCH("max_bwd", (k_max_bwd), col_grid(S, 1), dim3(DPC_BLOCK, 1, 1), 0, st, grid_blur, scale, dproj, first,
-                 dscale, S.Dz, S.D, 1);
+                 ds_acc, S.Dz, S.D, 1);
       rc = last_error();
     }
     if (rc) return rc;
@@ -1696,8 +1957,9 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
     dg = tB;
   }
   // 3. sparse x-blur + clip mask + gather + transform VJP + reductions
-  return launch_points_bwd(st, S, P, pc, pose, trans, focal, tr_pc, dg, grid_raw, taps_x, dtr_pc_in, true,
-                           dpc, dpose, dtrans, dfocal, accum);
+  return launch_points_bwd(st, S, P, pc, pose, trans, focal, tr_pc, dg, use_cmask ? nullptr : grid_raw,
+                           use_cmask ? clip_mask : nullptr, taps_x, dtr_pc_in, true, dpc, dpose, dtrans, dfocal,
+                           scale ? dscale : nullptr, accum, false);
 }
 
 }  // extern "C"

@@ -81,6 +81,8 @@ static inline float atomicAdd(float* p, float v) {
   }
 }
 
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
 // wave64 shuffles through the exchange buffer (block-uniform control flow only)
 static inline float __shfl_down(float v, unsigned delta, int width = 64) {
   (void)width;
