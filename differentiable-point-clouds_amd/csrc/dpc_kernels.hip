@@ -46,6 +46,15 @@
 
 #include <math.h>
 
+// Lanes of one wave execute in lock-step on the GPU; the thread-per-lane CPU
+// emulation needs an explicit rendezvous where a wave reads and then overwrites
+// the same LDS row.
+#ifdef DPC_EMU
+#define DPC_WAVE_SYNC() __syncthreads()
+#else
+#define DPC_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
 #include <mutex>
 #include <vector>
 
@@ -848,7 +857,9 @@ k_zsort(DpcShape S, const float* __restrict__ tr_pc, int* __restrict__ order, in
   }
 }
 
-// WG = (view b, plane z, y-strip).  LDS tile = rows [y0-h, y0+SH+h) x D.
+// WG = (view b, plane z, y-strip).  LDS tile = rows [y0-h, y0+SH+h), each row
+// D floats framed by PAD zero floats on both sides (PAD = 4*ceil(h/4)), so the
+// x-blur reads its halo as aligned 16-byte quads straight from LDS.
 template <int KC>
 __global__ void __launch_bounds__(DPC_BLOCK)
 k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ order,
@@ -858,7 +869,10 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
   DPC_DYN_SMEM(float, tile);
   constexpr int h = KC / 2;
   constexpr int G = zgroup(KC);
+  constexpr int NQ = (h + 3) / 4;   // halo quads per side
+  constexpr int PAD = 4 * NQ;
   const int D = S.D, Dz = S.Dz, N = S.N;
+  const int PT = D + 2 * PAD;
   const int bid = blockIdx.x;
   const int strip = bid % nstrips;
   const int pz = bid / nstrips;
@@ -867,8 +881,8 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
   const int RT = SH + 2 * h;
   const int tid = threadIdx.x, nth = blockDim.x;
 
-  // 1. zero the tile
-  for (int i = tid * 4; i < RT * D; i += nth * 4)
+  // 1. zero the tile (pads included)
+  for (int i = tid * 4; i < RT * PT; i += nth * 4)
     *reinterpret_cast<float4*>(tile + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
 
@@ -891,7 +905,7 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
 #pragma unroll
       for (int l = 0; l < 2; ++l) {
         const int xx = c.ix + l;
-        if (xx < D) atomicAdd(&tile[t * D + xx], wz * wy[j] * wx[l]);
+        if (xx < D) atomicAdd(&tile[t * PT + PAD + xx], wz * wy[j] * wx[l]);
       }
     }
   }
@@ -912,7 +926,7 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
       for (int l = 0; l < 2; ++l) {
         const int xx = c.ix + l;
         if (xx < D) {
-          const float g0 = tile[t * D + xx];
+          const float g0 = tile[t * PT + PAD + xx];
           bits |= (g0 >= 0.f && g0 <= 1.f) ? (1u << l) : 0u;
         }
       }
@@ -921,7 +935,8 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
   }
   __syncthreads();
 
-  // 4. clip + x-blur, rows in place (halo from neighbour lanes, as in k_blur_xy_stream)
+  // 4. clip + x-blur, rows in place.  A row belongs to one stream (= LR lanes of
+  //    one wave), which reads all its quads before writing, so in-place is safe.
   const int lane = tid & 63, wave = tid >> 6;
   const int LR = 1 << lr_shift;
   const int PL = 64 >> lr_shift;
@@ -931,34 +946,28 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
   float tpx[KC];
 #pragma unroll
   for (int m = 0; m < KC; ++m) tpx[m] = taps_x[m];
-  for (int t0 = 0; t0 < RT; t0 += nstream) {
+  for (int t0 = 0; t0 < RT; t0 += nstream) {  // uniform trip count
     const int t = t0 + stream;
     const bool rowok = t < RT;
-    float v[4], xb[4];
-    load_cx<4>(tile + (rowok ? t : 0) * D + lx * 4, v);
+    float* row = tile + (rowok ? t : 0) * PT + PAD + lx * 4;
+    float w[4 * (2 * NQ + 1)];  // w[i] <-> x = 4*lx - PAD + i
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = rowok ? clampf(v[c], 0.f, 1.f) : 0.f;
-    float w[4 + 2 * h];
+    for (int q = 0; q < 2 * NQ + 1; ++q) {
+      float v[4];
+      load_cx<4>(row + 4 * (q - NQ), v);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) w[h + c] = v[c];
-#pragma unroll
-    for (int e = 1; e <= h; ++e) {
-      const int dl = (e + 3) / 4;
-      const int jl = (4 * dl - e) & 3;
-      const float vl = __shfl(v[jl], (lane - dl) & 63, 64);
-      w[h - e] = (lx - dl >= 0) ? vl : 0.f;
-      const int jr = (e - 1) & 3;
-      const float vr = __shfl(v[jr], (lane + dl) & 63, 64);
-      w[h + 3 + e] = (lx + dl < LR) ? vr : 0.f;
+      for (int c = 0; c < 4; ++c) w[4 * q + c] = clampf(v[c], 0.f, 1.f);
     }
+    float xb[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       float a = 0.f;
 #pragma unroll
-      for (int m = 0; m < KC; ++m) a += tpx[m] * w[o + m];
+      for (int m = 0; m < KC; ++m) a += tpx[m] * w[PAD - h + o + m];
       xb[o] = a;
     }
-    if (rowok) store_cx<4>(tile + t * D + lx * 4, xb);
+    DPC_WAVE_SYNC();  // all lanes of the row have read their quads (lock-step on hardware)
+    if (rowok) store_cx<4>(row, xb);
   }
   __syncthreads();
 
@@ -974,7 +983,7 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
       const int q = q0 + u;
       if (q < steps) {
         float v[4], o[4];
-        load_cx<4>(tile + (stream * RS + q) * D + lx * 4, v);
+        load_cx<4>(tile + (stream * RS + q) * PT + PAD + lx * 4, v);
         fir.push(v, o, u);
         const int gy = y0 + stream * RS + q - 2 * h;
         if (q >= 2 * h && gy < D) store_cx<4>(oplane + (size_t)gy * D + lx * 4, o);
@@ -1098,12 +1107,7 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
     Qs[c] = 0.0;
   }
   const int T = Dz + h;
-  float cur[G][CX], nxt[G][CX];
-#pragma unroll
-  for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, u, Dz, cur[u]);
-  for (int t0 = 0; t0 < T; t0 += G) {
-#pragma unroll
-    for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, t0 + G + u, Dz, nxt[u]);
+  auto process = [&](const float (&buf)[G][CX], int t0) {
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       const int t = t0 + u;
@@ -1111,7 +1115,7 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
         float v[CX], g2[CX];
 #pragma unroll
         for (int c = 0; c < CX; ++c) {
-          const float r = (t < Dz) ? cur[u][c] : 0.f;
+          const float r = (t < Dz) ? buf[u][c] : 0.f;
           v[c] = clip_in ? clampf(r, 0.f, 1.f) : r;
         }
         fir.push(v, g2, u);
@@ -1134,10 +1138,18 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
         }
       }
     }
+  };
+  // two groups of planes in flight, roles alternate (no register copies)
+  float bufA[G][CX], bufB[G][CX];
 #pragma unroll
-    for (int u = 0; u < G; ++u)
+  for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, u, Dz, bufA[u]);
+  for (int t0 = 0; t0 < T; t0 += 2 * G) {
 #pragma unroll
-      for (int c = 0; c < CX; ++c) cur[u][c] = nxt[u][c];
+    for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, t0 + G + u, Dz, bufB[u]);
+    process(bufA, t0);
+#pragma unroll
+    for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, t0 + 2 * G + u, Dz, bufA[u]);
+    process(bufB, t0 + G);
   }
   float pl[CX], pj[CX], dp[CX];
 #pragma unroll
@@ -1190,12 +1202,11 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
     const float s = has_s ? scale[b] : 1.0f;
     const float fDz = (float)Dz;
     float g[CX], gd[CX], Tr[CX];
-    double tot[CX], A[CX];
+    double tot[CX];
 #pragma unroll
     for (int c = 0; c < CX; ++c) {
       g[c] = dproj ? dproj[(size_t)b * ncol + ocol + c] : 0.f;
       gd[c] = ddepth ? ddepth[(size_t)b * ncol + ocol + c] : 0.f;
-      A[c] = 0.0;
       Tr[c] = 1.0f;
     }
     if (sums && !dprobs) {
@@ -1235,12 +1246,8 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
     ZFir<KC, CX> fir;
     fir.init(taps);
     const int T = Dz + h;
-    float cur[G][CX], nxt[G][CX];
-#pragma unroll
-    for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, u, Dz, cur[u]);
-    for (int t0 = 0; t0 < T; t0 += G) {
-#pragma unroll
-      for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, t0 + G + u, Dz, nxt[u]);
+    // rem = total - sum_{i<=j} a_i, kept in float64 (no cancellation error)
+    auto process = [&](const float (&buf)[G][CX], int t0) {
 #pragma unroll
       for (int u = 0; u < G; ++u) {
         const int j = t0 + u;
@@ -1250,7 +1257,7 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
             const float psi = (float)j / fDz - 0.5f + P.camera_distance;
 #pragma unroll
             for (int c = 0; c < CX; ++c) {
-              const float vv = cur[u][c];
+              const float vv = buf[u][c];
               const float sg = vv * s;
               const float g3 = has_s ? clampf(sg, 0.f, 1.f) : vv;
               const float cc = clampf(g3, eps, one_m);
@@ -1258,14 +1265,13 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
               const float Tq = (j == 0) ? e_eps : Tr[c];
               float gam = g[c] + gd[c] * psi;
               if (dprobs) gam += dprobs[((size_t)j * B + b) * ncol + ocol + c];
-              const float gT = gam * Tq;                 // = a_j / c_j
-              A[c] += (double)(gT * cc);                  // a_j = gamma_j p_j
-              const float suffix = (float)(tot[c] - A[c]);
-              const float dc = gT - __fdividef(suffix, omc);
-              const float dg3 = (g3 >= eps && g3 <= one_m) ? dc : 0.f;
+              const float gT = gam * Tq;           // = a_j / c_j
+              tot[c] -= (double)(gT * cc);          // a_j = gamma_j p_j
+              const float dc = gT - __fdividef((float)tot[c], omc);
+              const float dg3 = (cc == g3) ? dc : 0.f;   // eps <= G3 <= 1-eps  <=>  the clip was inactive
               Tr[c] *= omc;
               if (has_s) {
-                const bool m2 = (sg >= 0.f) && (sg <= 1.f);
+                const bool m2 = (g3 == sg);          // 0 <= s G2 <= 1        <=>  the clip was inactive
                 dg2[c] = m2 ? s * dg3 : 0.f;
                 dsacc[0] += m2 ? vv * dg3 : 0.f;
               } else {
@@ -1280,10 +1286,17 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
           if (j >= h) store_cx<CX>(dgz + base + (size_t)(j - h) * ncol, o);
         }
       }
+    };
+    float bufA[G][CX], bufB[G][CX];
 #pragma unroll
-      for (int u = 0; u < G; ++u)
+    for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, u, Dz, bufA[u]);
+    for (int t0 = 0; t0 < T; t0 += 2 * G) {
 #pragma unroll
-        for (int c = 0; c < CX; ++c) cur[u][c] = nxt[u][c];
+      for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, t0 + G + u, Dz, bufB[u]);
+      process(bufA, t0);
+#pragma unroll
+      for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, t0 + 2 * G + u, Dz, bufA[u]);
+      process(bufB, t0 + G);
     }
   }
   if (dscale) {  // uniform across the grid
@@ -1601,14 +1614,15 @@ SplatPlan splat_plan(const DpcShape& S) {
   int lr_shift = 0;
   while ((4 << lr_shift) < D) ++lr_shift;
   const int nstream = (DPC_BLOCK / 64) * (64 >> lr_shift);
+  const int PT = D + 2 * 4 * ((K / 2 + 3) / 4);  // row pitch incl. zero pads (see k_splat_xy)
   int SH = D;
-  while (SH >= nstream && sizeof(float) * (size_t)(SH + 2 * (K / 2)) * D > 48 * 1024) SH >>= 1;
+  while (SH >= nstream && sizeof(float) * (size_t)(SH + 2 * (K / 2)) * PT > 48 * 1024) SH >>= 1;
   if (SH < nstream || SH % nstream != 0) return p;
   p.ok = true;
   p.SH = SH;
   p.nstrips = D / SH;
   p.lr_shift = lr_shift;
-  p.lds_bytes = sizeof(float) * (size_t)(SH + 2 * (K / 2)) * D;
+  p.lds_bytes = sizeof(float) * (size_t)(SH + 2 * (K / 2)) * PT;
   return p;
 }
 inline size_t splat_index_bytes(const DpcShape& S) {
