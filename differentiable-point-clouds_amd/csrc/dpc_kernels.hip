@@ -49,6 +49,12 @@
 // Lanes of one wave execute in lock-step on the GPU; the thread-per-lane CPU
 // emulation needs an explicit rendezvous where a wave reads and then overwrites
 // the same LDS row.
+#ifndef DPC_PINGPONG
+#define DPC_PINGPONG 0
+#endif
+#ifndef DPC_SPLAT_SHFL
+#define DPC_SPLAT_SHFL 0
+#endif
 #ifdef DPC_EMU
 #define DPC_WAVE_SYNC() __syncthreads()
 #else
@@ -857,9 +863,7 @@ k_zsort(DpcShape S, const float* __restrict__ tr_pc, int* __restrict__ order, in
   }
 }
 
-// WG = (view b, plane z, y-strip).  LDS tile = rows [y0-h, y0+SH+h), each row
-// D floats framed by PAD zero floats on both sides (PAD = 4*ceil(h/4)), so the
-// x-blur reads its halo as aligned 16-byte quads straight from LDS.
+// WG = (view b, plane z, y-strip).  LDS tile = rows [y0-h, y0+SH+h) x D.
 template <int KC>
 __global__ void __launch_bounds__(DPC_BLOCK)
 k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ order,
@@ -869,10 +873,7 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
   DPC_DYN_SMEM(float, tile);
   constexpr int h = KC / 2;
   constexpr int G = zgroup(KC);
-  constexpr int NQ = (h + 3) / 4;   // halo quads per side
-  constexpr int PAD = 4 * NQ;
   const int D = S.D, Dz = S.Dz, N = S.N;
-  const int PT = D + 2 * PAD;
   const int bid = blockIdx.x;
   const int strip = bid % nstrips;
   const int pz = bid / nstrips;
@@ -881,8 +882,8 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
   const int RT = SH + 2 * h;
   const int tid = threadIdx.x, nth = blockDim.x;
 
-  // 1. zero the tile (pads included)
-  for (int i = tid * 4; i < RT * PT; i += nth * 4)
+  // 1. zero the tile
+  for (int i = tid * 4; i < RT * D; i += nth * 4)
     *reinterpret_cast<float4*>(tile + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
 
@@ -905,7 +906,7 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
 #pragma unroll
       for (int l = 0; l < 2; ++l) {
         const int xx = c.ix + l;
-        if (xx < D) atomicAdd(&tile[t * PT + PAD + xx], wz * wy[j] * wx[l]);
+        if (xx < D) atomicAdd(&tile[t * D + xx], wz * wy[j] * wx[l]);
       }
     }
   }
@@ -926,7 +927,7 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
       for (int l = 0; l < 2; ++l) {
         const int xx = c.ix + l;
         if (xx < D) {
-          const float g0 = tile[t * PT + PAD + xx];
+          const float g0 = tile[t * D + xx];
           bits |= (g0 >= 0.f && g0 <= 1.f) ? (1u << l) : 0u;
         }
       }
@@ -935,8 +936,7 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
   }
   __syncthreads();
 
-  // 4. clip + x-blur, rows in place.  A row belongs to one stream (= LR lanes of
-  //    one wave), which reads all its quads before writing, so in-place is safe.
+  // 4. clip + x-blur, rows in place (halo from neighbour lanes, as in k_blur_xy_stream)
   const int lane = tid & 63, wave = tid >> 6;
   const int LR = 1 << lr_shift;
   const int PL = 64 >> lr_shift;
@@ -946,28 +946,34 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
   float tpx[KC];
 #pragma unroll
   for (int m = 0; m < KC; ++m) tpx[m] = taps_x[m];
-  for (int t0 = 0; t0 < RT; t0 += nstream) {  // uniform trip count
+  for (int t0 = 0; t0 < RT; t0 += nstream) {
     const int t = t0 + stream;
     const bool rowok = t < RT;
-    float* row = tile + (rowok ? t : 0) * PT + PAD + lx * 4;
-    float w[4 * (2 * NQ + 1)];  // w[i] <-> x = 4*lx - PAD + i
+    float v[4], xb[4];
+    load_cx<4>(tile + (rowok ? t : 0) * D + lx * 4, v);
 #pragma unroll
-    for (int q = 0; q < 2 * NQ + 1; ++q) {
-      float v[4];
-      load_cx<4>(row + 4 * (q - NQ), v);
+    for (int c = 0; c < 4; ++c) v[c] = rowok ? clampf(v[c], 0.f, 1.f) : 0.f;
+    float w[4 + 2 * h];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) w[4 * q + c] = clampf(v[c], 0.f, 1.f);
+    for (int c = 0; c < 4; ++c) w[h + c] = v[c];
+#pragma unroll
+    for (int e = 1; e <= h; ++e) {
+      const int dl = (e + 3) / 4;
+      const int jl = (4 * dl - e) & 3;
+      const float vl = __shfl(v[jl], (lane - dl) & 63, 64);
+      w[h - e] = (lx - dl >= 0) ? vl : 0.f;
+      const int jr = (e - 1) & 3;
+      const float vr = __shfl(v[jr], (lane + dl) & 63, 64);
+      w[h + 3 + e] = (lx + dl < LR) ? vr : 0.f;
     }
-    float xb[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       float a = 0.f;
 #pragma unroll
-      for (int m = 0; m < KC; ++m) a += tpx[m] * w[PAD - h + o + m];
+      for (int m = 0; m < KC; ++m) a += tpx[m] * w[o + m];
       xb[o] = a;
     }
-    DPC_WAVE_SYNC();  // all lanes of the row have read their quads (lock-step on hardware)
-    if (rowok) store_cx<4>(row, xb);
+    if (rowok) store_cx<4>(tile + t * D + lx * 4, xb);
   }
   __syncthreads();
 
@@ -983,7 +989,7 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
       const int q = q0 + u;
       if (q < steps) {
         float v[4], o[4];
-        load_cx<4>(tile + (stream * RS + q) * PT + PAD + lx * 4, v);
+        load_cx<4>(tile + (stream * RS + q) * D + lx * 4, v);
         fir.push(v, o, u);
         const int gy = y0 + stream * RS + q - 2 * h;
         if (q >= 2 * h && gy < D) store_cx<4>(oplane + (size_t)gy * D + lx * 4, o);
@@ -1143,6 +1149,7 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
   float bufA[G][CX], bufB[G][CX];
 #pragma unroll
   for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, u, Dz, bufA[u]);
+#if DPC_PINGPONG
   for (int t0 = 0; t0 < T; t0 += 2 * G) {
 #pragma unroll
     for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, t0 + G + u, Dz, bufB[u]);
@@ -1151,6 +1158,17 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
     for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, t0 + 2 * G + u, Dz, bufA[u]);
     process(bufB, t0 + G);
   }
+#else
+  for (int t0 = 0; t0 < T; t0 += G) {
+#pragma unroll
+    for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, t0 + G + u, Dz, bufB[u]);
+    process(bufA, t0);
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+#pragma unroll
+      for (int c = 0; c < CX; ++c) bufA[u][c] = bufB[u][c];
+  }
+#endif
   float pl[CX], pj[CX], dp[CX];
 #pragma unroll
   for (int c = 0; c < CX; ++c) {
@@ -1290,6 +1308,7 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
     float bufA[G][CX], bufB[G][CX];
 #pragma unroll
     for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, u, Dz, bufA[u]);
+#if DPC_PINGPONG
     for (int t0 = 0; t0 < T; t0 += 2 * G) {
 #pragma unroll
       for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, t0 + G + u, Dz, bufB[u]);
@@ -1298,6 +1317,17 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
       for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, t0 + 2 * G + u, Dz, bufA[u]);
       process(bufB, t0 + G);
     }
+#else
+    for (int t0 = 0; t0 < T; t0 += G) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, t0 + G + u, Dz, bufB[u]);
+      process(bufA, t0);
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+#pragma unroll
+        for (int c = 0; c < CX; ++c) bufA[u][c] = bufB[u][c];
+    }
+#endif
   }
   if (dscale) {  // uniform across the grid
     block_reduce_sum<1>(dsacc);
@@ -1614,15 +1644,14 @@ SplatPlan splat_plan(const DpcShape& S) {
   int lr_shift = 0;
   while ((4 << lr_shift) < D) ++lr_shift;
   const int nstream = (DPC_BLOCK / 64) * (64 >> lr_shift);
-  const int PT = D + 2 * 4 * ((K / 2 + 3) / 4);  // row pitch incl. zero pads (see k_splat_xy)
   int SH = D;
-  while (SH >= nstream && sizeof(float) * (size_t)(SH + 2 * (K / 2)) * PT > 48 * 1024) SH >>= 1;
+  while (SH >= nstream && sizeof(float) * (size_t)(SH + 2 * (K / 2)) * D > 48 * 1024) SH >>= 1;
   if (SH < nstream || SH % nstream != 0) return p;
   p.ok = true;
   p.SH = SH;
   p.nstrips = D / SH;
   p.lr_shift = lr_shift;
-  p.lds_bytes = sizeof(float) * (size_t)(SH + 2 * (K / 2)) * PT;
+  p.lds_bytes = sizeof(float) * (size_t)(SH + 2 * (K / 2)) * D;
   return p;
 }
 inline size_t splat_index_bytes(const DpcShape& S) {
