@@ -373,6 +373,7 @@ __device__ __forceinline__ void scatter_point(float* __restrict__ grid, int b, i
 // evaluated here, only at the <= 8 touched cells, and `mask` (= G0, dense) or
 // `cmask` (per-point corner bits) applies the clip_by_value(.,0,1) gradient
 // mask of point_cloud.py:240.
+template <int KC>
 __device__ __forceinline__ void gather_point(const float* __restrict__ dgrid,
                                              const float* __restrict__ mask,
                                              const unsigned char* __restrict__ cmask /*4 bytes of this point*/,
@@ -396,7 +397,23 @@ __device__ __forceinline__ void gather_point(const float* __restrict__ dgrid,
       if (zz >= Dz || yy >= D) continue;
       const size_t row = base_b + ((size_t)zz * D + yy) * D;
       float g[2] = {0.f, 0.f};
-      if (Kx > 0) {
+      if (KC > 0) {
+        // compile-time K: all K+1 window loads are unconditional (clamped address,
+        // value zeroed when outside the row) so they are issued back to back
+        float win[(KC > 0 ? KC : 1) + 1];
+#pragma unroll
+        for (int m = 0; m <= KC; ++m) {
+          const int x = c.ix - KC / 2 + m;
+          const int xc = x < 0 ? 0 : (x >= D ? D - 1 : x);
+          const float val = dgrid[row + xc];
+          win[m] = (x == xc) ? val : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < KC; ++m) {
+          g[0] += taps_x[m] * win[m];
+          g[1] += taps_x[m] * win[m + 1];
+        }
+      } else if (Kx > 0) {
         // window x in [ix-h, ix+1+h]; tap m of output l sits at x = ix + l + m - h
         for (int m = 0; m <= Kx; ++m) {
           const int x = c.ix - h + m;
@@ -471,7 +488,7 @@ k_gather(DpcShape S, const float* __restrict__ tr_pc, const float* __restrict__ 
   if (n >= S.N) return;
   const size_t o = ((size_t)b * S.N + n) * 3;
   float dw, dv, du;
-  gather_point(dgrid, nullptr, nullptr, nullptr, 0, b, S.Dz, S.D, tr_pc[o], tr_pc[o + 1], tr_pc[o + 2], dw, dv, du);
+  gather_point<0>(dgrid, nullptr, nullptr, nullptr, 0, b, S.Dz, S.D, tr_pc[o], tr_pc[o + 1], tr_pc[o + 2], dw, dv, du);
   dtr_pc[o] = dw;
   dtr_pc[o + 1] = dv;
   dtr_pc[o + 2] = du;
@@ -479,7 +496,7 @@ k_gather(DpcShape S, const float* __restrict__ tr_pc, const float* __restrict__ 
 
 // Gather (+ sparse x-blur + clip mask) + camera-transform VJP + per-instance
 // reductions.  GATHER=false: d(tr_pc) is read from dtr_in instead.
-template <bool QUAT, bool GATHER>
+template <bool QUAT, bool GATHER, int KC>
 __global__ void __launch_bounds__(DPC_BLOCK)
 k_points_bwd(DpcShape S, DpcParams P, const float* __restrict__ pc, const float* __restrict__ pose,
              const float* __restrict__ trans, const float* __restrict__ focal,
@@ -498,7 +515,7 @@ k_points_bwd(DpcShape S, DpcParams P, const float* __restrict__ pc, const float*
     const size_t o = ((size_t)b * S.N + n) * 3;
     float dw = 0.f, dv = 0.f, du = 0.f;
     if (GATHER)
-      gather_point(dgrid, mask, cmask ? cmask + ((size_t)b * S.N + n) * 4 : nullptr, taps_x, S.Kx, b, S.Dz, S.D,
+      gather_point<KC>(dgrid, mask, cmask ? cmask + ((size_t)b * S.N + n) * 4 : nullptr, taps_x, S.Kx, b, S.Dz, S.D,
                    tr_pc[o], tr_pc[o + 1], tr_pc[o + 2], dw, dv, du);
     if (dtr_in) {
       dw += dtr_in[o];
@@ -864,7 +881,7 @@ k_zsort(DpcShape S, const float* __restrict__ tr_pc, int* __restrict__ order, in
 }
 
 // WG = (view b, plane z, y-strip).  LDS tile = rows [y0-h, y0+SH+h) x D.
-template <int KC>
+template <int KC, int VY>
 __global__ void __launch_bounds__(DPC_BLOCK)
 k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ order,
            const int* __restrict__ zstart, const float* __restrict__ taps_x,
@@ -977,9 +994,15 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
   }
   __syncthreads();
 
-  // 5. y-blur: each stream produces RS output rows, register FIR over RS + 2h tile rows
-  const int RS = SH / nstream;
-  ZFir<KC, 4> fir;
+  // 5. y-blur: each stream produces RS output rows with a register FIR over RS + 2h
+  //    tile rows.  VY floats per lane: narrower lanes = fewer, longer streams = less
+  //    halo redundancy (RS + 2h pushes per RS outputs).
+  const int LRy = D / VY;                 // lanes per row (power of two <= 64)
+  const int sy = (wave * 64 + lane) / LRy;  // stream id
+  const int ly = lane & (LRy - 1);
+  const int nsy = nth / LRy;
+  const int RS = SH / nsy;
+  ZFir<KC, VY> fir;
   fir.init(taps_y);
   const int steps = RS + 2 * h;
   float* oplane = out + (size_t)pz * D * D;
@@ -988,11 +1011,11 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
     for (int u = 0; u < G; ++u) {
       const int q = q0 + u;
       if (q < steps) {
-        float v[4], o[4];
-        load_cx<4>(tile + (stream * RS + q) * D + lx * 4, v);
+        float v[VY], o[VY];
+        load_cx<VY>(tile + (sy * RS + q) * D + ly * VY, v);
         fir.push(v, o, u);
-        const int gy = y0 + stream * RS + q - 2 * h;
-        if (q >= 2 * h && gy < D) store_cx<4>(oplane + (size_t)gy * D + lx * 4, o);
+        const int gy = y0 + sy * RS + q - 2 * h;
+        if (q >= 2 * h && gy < D) store_cx<VY>(oplane + (size_t)gy * D + ly * VY, o);
       }
     }
   }
@@ -1612,13 +1635,22 @@ int launch_points_bwd(hipStream_t st, const DpcShape& S, const DpcParams& P, con
   }
   const dim3 grid = point_grid(S), block(DPC_BLOCK, 1, 1);
   const bool quat = P.pose_is_quaternion != 0;
-#define DPC_PB(Q, G)                                                                                  \
-  DPC_LAUNCH("points_bwd", (k_points_bwd<Q, G>), grid, block, 0, st, S, P, pc, pose, trans, focal, tr_pc, dgrid, mask, \
-             cmask, taps_x, dtr_in, dpc, accum)
-  if (quat && gather) DPC_PB(true, true);
-  else if (quat) DPC_PB(true, false);
-  else if (gather) DPC_PB(false, true);
-  else DPC_PB(false, false);
+#define DPC_PB(Q, G, KC)                                                                              \
+  DPC_LAUNCH("points_bwd", (k_points_bwd<Q, G, KC>), grid, block, 0, st, S, P, pc, pose, trans, focal, tr_pc, dgrid, \
+             mask, cmask, taps_x, dtr_in, dpc, accum)
+  const int kc = (gather && (S.Kx == 5 || S.Kx == 11 || S.Kx == 21)) ? S.Kx : 0;
+  if (quat && gather) {
+    if (kc == 11) DPC_PB(true, true, 11);
+    else if (kc == 21) DPC_PB(true, true, 21);
+    else if (kc == 5) DPC_PB(true, true, 5);
+    else DPC_PB(true, true, 0);
+  } else if (quat) {
+    DPC_PB(true, false, 0);
+  } else if (gather) {
+    DPC_PB(false, true, 0);
+  } else {
+    DPC_PB(false, false, 0);
+  }
 #undef DPC_PB
   const dim3 fg((S.B + 63) / 64, 1, 1), fb(64, 1, 1);
   if (quat)
@@ -1633,11 +1665,11 @@ int launch_points_bwd(hipStream_t st, const DpcShape& S, const DpcParams& P, con
 // ---- fused front end (k_zsort + k_splat_xy) -------------------------------------
 struct SplatPlan {
   bool ok;
-  int SH, nstrips, lr_shift;
+  int SH, nstrips, lr_shift, vy;
   size_t lds_bytes;
 };
 SplatPlan splat_plan(const DpcShape& S) {
-  SplatPlan p = {false, 0, 0, 0, 0};
+  SplatPlan p = {false, 0, 0, 0, 0, 0};
   const int D = S.D, K = S.Kx;
   if (S.Kx != S.Ky || (K != 5 && K != 11 && K != 21)) return p;
   if (D < 32 || D > 256 || (D & (D - 1)) != 0 || S.N <= 0) return p;
@@ -1647,6 +1679,9 @@ SplatPlan splat_plan(const DpcShape& S) {
   int SH = D;
   while (SH >= nstream && sizeof(float) * (size_t)(SH + 2 * (K / 2)) * D > 48 * 1024) SH >>= 1;
   if (SH < nstream || SH % nstream != 0) return p;
+  p.vy = (D <= 128) ? 2 : 4;              // y-phase floats per lane (k_splat_xy step 5)
+  const int nsy = DPC_BLOCK / (D / p.vy);
+  if (nsy < 1 || SH % nsy != 0) return p;
   p.ok = true;
   p.SH = SH;
   p.nstrips = D / SH;
@@ -1667,12 +1702,18 @@ int launch_splat_xy(hipStream_t st, const DpcShape& S, const SplatPlan& pl, cons
   const long long nblk = (long long)S.B * S.Dz * pl.nstrips;
   if (nblk > 0x7fffffffLL) return DPC_E_SHAPE;
   const dim3 grid((unsigned)nblk, 1, 1), block(DPC_BLOCK, 1, 1);
-#define DPC_SP(KC)                                                                                         \
-  DPC_LAUNCH("splat_xy", (k_splat_xy<KC>), grid, block, pl.lds_bytes, st, S, tr_pc, (const int*)order,    \
+#define DPC_SP(KC, VY)                                                                                     \
+  DPC_LAUNCH("splat_xy", (k_splat_xy<KC, VY>), grid, block, pl.lds_bytes, st, S, tr_pc, (const int*)order, \
              (const int*)zstart, tx, ty, out, cmask, pl.SH, pl.nstrips, pl.lr_shift)
-  if (S.Kx == 5) DPC_SP(5);
-  else if (S.Kx == 11) DPC_SP(11);
-  else DPC_SP(21);
+#define DPC_SPV(KC)                \
+  do {                             \
+    if (pl.vy == 2) DPC_SP(KC, 2); \
+    else DPC_SP(KC, 4);            \
+  } while (0)
+  if (S.Kx == 5) DPC_SPV(5);
+  else if (S.Kx == 11) DPC_SPV(11);
+  else DPC_SPV(21);
+#undef DPC_SPV
 #undef DPC_SP
   return last_error();
 }
