@@ -1,0 +1,201 @@
+"""PyTorch counterpart of the projector-facing part of the reference model
+(dpc/models/model_pc.py): SURVEY.md 8(a) rows C1 (compute_projection and the
+multi-view / pose-candidate replication) and C2 (silhouette loss, min over pose
+candidates).  Same function and method names, argument meaning, instance order
+(model-major, then view, then candidate) and dict keys, so the parity tests
+read like the reference.
+
+The encoder / decoder / pose networks (dpc/nets/*) are NOT here: they stay
+stock PyTorch modules of the caller, whose outputs arrive in the `outputs`
+dict exactly as `model_predict` (model_pc.py:176-214) leaves them.  Everything
+in this file is thin device-side glue around `pointcloud_project_fast`.
+"""
+import math
+
+import torch
+
+from .util.gauss_kernel import smoothing_kernel
+from .util.point_cloud import pointcloud_project_fast
+
+
+def tf_repeat_0(input, num):  # noqa: A002  (reference name; model_pc.py:23-32)
+    """[a, b] -> [a, a, ..., b, b, ...]: repeat each leading-dim entry `num` times."""
+    return torch.repeat_interleave(input, int(num), dim=0)
+
+
+def get_smooth_sigma(cfg, global_step):
+    """model_pc.py:35-40: linear anneal pc_relative_sigma -> pc_relative_sigma_end."""
+    num_steps = cfg.max_number_of_steps
+    diff = cfg.pc_relative_sigma_end - cfg.pc_relative_sigma
+    return float(cfg.pc_relative_sigma + float(global_step) / num_steps * diff)
+
+
+def get_dropout_prob(cfg, global_step):
+    """model_pc.py:43-64: keep probability of the scheduled point dropout."""
+    if not cfg.pc_point_dropout_scheduled:
+        return float(cfg.pc_point_dropout)
+    keep_start, keep_end = float(cfg.pc_point_dropout), 1.0
+    start_step, end_step = cfg.pc_point_dropout_start_step, cfg.pc_point_dropout_end_step
+    x = float(global_step) / cfg.max_number_of_steps
+    if cfg.pc_point_dropout_exponential_schedule:
+        keep = keep_start * math.exp(math.log(keep_end / keep_start) * x)
+    else:
+        k = (keep_end - keep_start) / (end_step - start_step)
+        keep = k * x + (keep_start - k * start_step)
+    return float(min(max(keep, keep_start), keep_end))
+
+
+def resize_images_bilinear_tf1(images, size):
+    """tf.image.resize_images(..., BILINEAR), TF1 legacy sampling
+    (align_corners=False, no half-pixel centres): src = dst * in/out.
+    images [B,H,W,C] -> [B,size,size,C] (model_pc.py:392-397)."""
+    n, ih, iw, c = images.shape
+    oh, ow = int(size[0]), int(size[1])
+
+    def axis(o, i):
+        src = torch.arange(o, dtype=torch.float64, device=images.device) * (i / o)
+        lo = torch.floor(src).to(torch.int64)
+        hi = torch.clamp(lo + 1, max=i - 1)
+        return lo, hi, (src - lo.to(torch.float64)).to(images.dtype)
+    ylo, yhi, yl = axis(oh, ih)
+    xlo, xhi, xl = axis(ow, iw)
+    xl = xl.view(1, 1, -1, 1)
+    yl = yl.view(1, -1, 1, 1)
+    rows_lo, rows_hi = images[:, ylo], images[:, yhi]
+    top = rows_lo[:, :, xlo] * (1 - xl) + rows_lo[:, :, xhi] * xl
+    bot = rows_hi[:, :, xlo] * (1 - xl) + rows_hi[:, :, xhi] * xl
+    return top * (1 - yl) + bot * yl
+
+
+class ModelPointCloud(object):
+    """Projector + loss side of dpc/models/model_pc.py:130-445."""
+
+    def __init__(self, cfg, global_step=0, device=None):
+        self._params = cfg
+        self._global_step = global_step
+        self._device = device
+        self.setup_sigma()
+
+    def cfg(self):
+        return self._params
+
+    def setup_sigma(self):                                    # model_pc.py:146-153
+        cfg = self.cfg()
+        self._sigma_rel = get_smooth_sigma(cfg, self._global_step)
+        self._gauss_sigma = self._sigma_rel / cfg.vox_size
+        self._gauss_kernel = smoothing_kernel(cfg, self._sigma_rel, device=self._device)
+
+    def set_global_step(self, global_step):
+        self._global_step = global_step
+        self.setup_sigma()
+
+    def gauss_sigma(self):
+        return self._gauss_sigma
+
+    def gauss_kernel(self):
+        return self._gauss_kernel
+
+    def get_dropout_keep_prob(self):
+        return get_dropout_prob(self.cfg(), self._global_step)
+
+    def replicate_for_multiview(self, tensor):                # model_pc.py:261-264
+        return tf_repeat_0(tensor, self.cfg().step_size)
+
+    def replicate_outputs(self, outputs):
+        """The replication block of get_model_fn (model_pc.py:270-299): B models ->
+        B*step_size views -> x pose candidates.  Fills all_points,
+        all_scaling_factors, all_focal_length, all_rgb."""
+        cfg = self.cfg()
+        C = cfg.pose_predict_num_candidates
+        all_points = self.replicate_for_multiview(outputs["points_1"])
+        all_focal_length = None
+        if C > 1:
+            all_points = tf_repeat_0(all_points, C)
+            if cfg.predict_translation:
+                outputs["predicted_translation"] = tf_repeat_0(outputs["predicted_translation"], C)
+            if outputs.get("focal_length") is not None:
+                all_focal_length = tf_repeat_0(outputs["focal_length"], C)
+        outputs["all_focal_length"] = all_focal_length
+        outputs["all_points"] = all_points
+        if cfg.pc_learn_occupancy_scaling:
+            s = self.replicate_for_multiview(outputs["scaling_factor"])
+            if C > 1:
+                s = tf_repeat_0(s, C)
+        else:
+            s = None
+        outputs["all_scaling_factors"] = s
+        if cfg.pc_rgb:
+            raise NotImplementedError("RGB channels are SURVEY.md 8(f) scope")
+        outputs["all_rgb"] = None
+        return outputs
+
+    def compute_projection(self, inputs, outputs, is_training):   # model_pc.py:220-259
+        cfg = self.cfg()
+        all_points = outputs["all_points"]
+        all_rgb = outputs["all_rgb"]
+        if cfg.predict_pose:
+            camera_pose = outputs["poses"]
+        elif cfg.pose_quaternion:
+            camera_pose = inputs["camera_quaternion"]
+        else:
+            camera_pose = inputs["matrices"]
+        if is_training and cfg.pc_point_dropout != 1:
+            raise NotImplementedError("device-side point dropout is SURVEY.md 8(f) scope")
+        if not cfg.pc_fast:
+            raise NotImplementedError("slow exact-Gaussian path (pc_fast=false) is SURVEY.md 8(f) scope")
+        predicted_translation = outputs["predicted_translation"] if cfg.predict_translation else None
+        proj_out = pointcloud_project_fast(cfg, all_points, camera_pose, predicted_translation, all_rgb,
+                                           self.gauss_kernel(), scaling_factor=outputs["all_scaling_factors"],
+                                           focal_length=outputs["all_focal_length"])
+        proj = proj_out["proj"]
+        outputs["projs_rgb"] = proj_out["proj_rgb"]
+        # TF1 only computes drc_probs ([Dz+1,B,D,D,1]) if a loss fetches it; here it is
+        # materialised only when such a loss is switched on, and reachable via proj_out otherwise
+        outputs["proj_out"] = proj_out
+        outputs["drc_probs"] = proj_out["drc_probs"] if getattr(cfg, "drc_weight", 0.0) else None
+        outputs["projs_depth"] = proj_out["proj_depth"]
+        outputs["projs"] = proj
+        batch_size = outputs["points_1"].shape[0]
+        outputs["projs_1"] = proj[0:batch_size]
+        return outputs
+
+    def proj_loss_pose_candidates(self, gt, pred, inputs):     # model_pc.py:308-337
+        """gt [B*V,S,S,1], pred [B*V*C,S,S,1] -> (loss, winning candidate [B*V])."""
+        cfg = self.cfg()
+        C = cfg.pose_predict_num_candidates
+        gt = tf_repeat_0(gt, C)
+        sq_diff = (gt - pred) ** 2
+        all_loss = sq_diff.sum(dim=(1, 2, 3)).reshape(-1, C)
+        min_loss = torch.argmin(all_loss, dim=1)
+        mask = torch.nn.functional.one_hot(min_loss, C).to(pred.dtype)
+        num_samples = mask.shape[0]
+        loss_tensor = (gt - pred) * mask.reshape(-1, 1, 1, 1)
+        if cfg.variable_num_views:
+            w = tf_repeat_0(inputs["valid_samples"], C)
+            loss_tensor = loss_tensor * w.reshape(-1, 1, 1, 1)
+        proj_loss = (loss_tensor ** 2).sum() / 2 / float(num_samples)      # tf.nn.l2_loss
+        return proj_loss, min_loss
+
+    def add_proj_loss(self, inputs, outputs, weight_scale, add_summary=False):   # model_pc.py:383-423
+        cfg = self.cfg()
+        gt = inputs["masks"]
+        pred = outputs["projs"]
+        num_samples = pred.shape[0]
+        gt_size, pred_size = gt.shape[1], pred.shape[1]
+        assert gt_size >= pred_size, "GT size should not be higher than prediction size"
+        if gt_size > pred_size:
+            if cfg.bicubic_gt_downsampling:
+                raise NotImplementedError("bicubic GT downsampling")
+            gt = resize_images_bilinear_tf1(gt, [pred_size, pred_size])
+        if cfg.pc_gauss_filter_gt:
+            raise NotImplementedError("Gaussian-filtered GT (off by default, default_config.yaml:93)")
+        total_loss = 0
+        if cfg.pose_predict_num_candidates > 1:
+            proj_loss, min_loss = self.proj_loss_pose_candidates(gt, pred, inputs)
+            outputs["winning_pose_candidates"] = min_loss
+            if cfg.pose_predictor_student:
+                raise NotImplementedError("pose student loss (needs the pose network, out of scope)")
+        else:
+            proj_loss = ((gt - pred) ** 2).sum() / 2 / float(num_samples)
+        total_loss = total_loss + proj_loss
+        return total_loss * weight_scale

@@ -31,6 +31,12 @@ class Config(dict):
         pc_point_dropout=1.0, pc_learn_occupancy_scaling=True,
         pose_predict_num_candidates=1, step_size=4, batch_size=8,
         pc_num_points=8000, learn_focal_length=False,
+        pc_point_dropout_scheduled=True, pc_point_dropout_exponential_schedule=False,
+        pc_point_dropout_start_step=0.0, pc_point_dropout_end_step=1.0,
+        pose_predictor_student=True, variable_num_views=False,
+        # loss side (model_pc.py:383-445)
+        bicubic_gt_downsampling=False, pc_gauss_filter_gt=False,
+        proj_weight=1.0, drc_weight=0.0, proj_depth_weight=0.0,
     )
 
     def __init__(self, **kw):

@@ -299,11 +299,11 @@ def sqrt(x):
 
 
 def exp(x):
-    return _wrap(_torch.exp(x))
+    return _wrap(_torch.exp(_t(x)))
 
 
 def log(x):
-    return _wrap(_torch.log(x))
+    return _wrap(_torch.log(_t(x)))
 
 
 def multiply(a, b):
@@ -386,3 +386,87 @@ class _NN(object):
 
 
 nn = _NN()
+
+
+# ---------------------------------------------------------------------------
+# extras needed to import dpc/models/model_pc.py (caller rows C1/C2)
+# ---------------------------------------------------------------------------
+def to_float(x):
+    return _wrap(_t(x).to(_FLOAT) if isinstance(x, _torch.Tensor) else _torch.tensor(float(x), dtype=_FLOAT))
+
+
+def argmin(x, axis=None):
+    return _wrap(_torch.argmin(x, dim=axis))
+
+
+def one_hot(indices, depth):
+    return _wrap(_torch.nn.functional.one_hot(indices.to(_torch.int64), int(depth)).to(_FLOAT))
+
+
+def sigmoid(x):
+    return _wrap(_torch.sigmoid(x))
+
+
+def reduce_mean(x, axis=None, keepdims=False):
+    return _wrap(_torch.mean(x) if axis is None else _torch.mean(x, dim=_axes(axis), keepdim=keepdims))
+
+
+def less(a, b):
+    return _wrap(_t(a) < _t(b))
+
+
+def where(c, a, b):
+    return _wrap(_torch.where(c, a, b))
+
+
+class _Image(object):
+    class ResizeMethod(object):
+        BILINEAR = 0
+        BICUBIC = 2
+
+    @staticmethod
+    def resize_images(images, size, method=0):
+        """TF1 tf.image.resize_images, align_corners=False (legacy): source
+        coordinate = dst * (in/out), no half-pixel offset, bilinear."""
+        assert method == 0, "only bilinear"
+        n, ih, iw, c = [int(s) for s in images.size()]
+        oh, ow = int(size[0]), int(size[1])
+
+        def axis(o, i):
+            src = _torch.arange(o, dtype=_torch.float64) * (i / o)
+            lo = _torch.floor(src).to(_torch.int64)
+            hi = _torch.clamp(lo + 1, max=i - 1)
+            return lo, hi, (src - lo.to(_torch.float64)).to(images.dtype)
+        ylo, yhi, yl = axis(oh, ih)
+        xlo, xhi, xl = axis(ow, iw)
+        top = images[:, ylo][:, :, xlo] * (1 - xl).view(1, 1, -1, 1) + images[:, ylo][:, :, xhi] * xl.view(1, 1, -1, 1)
+        bot = images[:, yhi][:, :, xlo] * (1 - xl).view(1, 1, -1, 1) + images[:, yhi][:, :, xhi] * xl.view(1, 1, -1, 1)
+        return _wrap(top * (1 - yl).view(1, -1, 1, 1) + bot * yl.view(1, -1, 1, 1))
+
+
+image = _Image()
+
+
+def _l2_loss(x):
+    return _wrap((x * x).sum() / 2)
+
+
+_NN.l2_loss = staticmethod(_l2_loss)
+
+
+class _Noop(object):
+    """tf.contrib.{slim,summary}: import-time attribute access and summary
+    calls only; nothing on the projector/loss path computes through them."""
+
+    def __getattr__(self, name):
+        return _Noop()
+
+    def __call__(self, *a, **k):
+        return None
+
+
+contrib = _Noop()
+
+
+def truncated_normal_initializer(*a, **k):
+    return None

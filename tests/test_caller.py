@@ -1,0 +1,79 @@
+"""Caller rows C1/C2: the PyTorch counterpart of
+ModelPointCloud.compute_projection / add_proj_loss against goldens produced by
+the reference's own model_pc.py (tests/golden/make_caller_goldens.py): instance
+ordering (model-major -> view -> candidate), kwargs, output keys, loss value,
+gradients, and the sigma / dropout schedules."""
+import numpy as np
+import pytest
+import torch
+
+import dpc_amd
+from dpc_amd import model_pc as M
+from helpers import load, maxabs, relerr
+
+
+def _cfg(g):
+    return dpc_amd.default_config(vox_size=int(g["D"]), pc_gauss_kernel_size=int(g["K"]), pc_relative_sigma=3.0,
+                                  pc_relative_sigma_end=0.2, predict_pose=True, pose_predict_num_candidates=int(g["C"]),
+                                  step_size=int(g["V"]), batch_size=int(g["Bm"]), pose_predictor_student=False)
+
+
+def _run(dev):
+    g = load("caller_toy")
+    cfg = _cfg(g)
+    model = M.ModelPointCloud(cfg, global_step=int(g["global_step"]), device=dev)
+    t = lambda k, grad=True: torch.tensor(g[k], device=dev, requires_grad=grad)
+    pts, poses, scal = t("points_1"), t("poses"), t("scaling_factor")
+    outputs = {"points_1": pts, "poses": poses, "scaling_factor": scal, "focal_length": None}
+    outputs = model.replicate_outputs(outputs)
+    inputs = {"masks": t("masks", False)}
+    outputs = model.compute_projection(inputs, outputs, is_training=False)
+    loss = model.add_proj_loss(inputs, outputs, cfg.proj_weight)
+    loss.backward()
+    return g, model, outputs, loss, pts, poses, scal
+
+
+def _check(g, model, outputs, loss, pts, poses, scal):
+    assert abs(model._sigma_rel - float(g["sigma_rel_f64"])) < 1e-6
+    assert maxabs(outputs["all_points"].detach().cpu().numpy(), g["all_points_f32"]) == 0.0   # ordering
+    assert maxabs(outputs["projs"].detach().cpu().numpy(), g["projs_f64"]) < 2e-5
+    assert maxabs(outputs["projs_depth"].detach().cpu().numpy(), g["projs_depth_f64"]) < 2e-4
+    assert maxabs(outputs["projs_1"].detach().cpu().numpy(), g["projs_1_f64"]) < 2e-5
+    assert outputs["projs_rgb"] is None and outputs["drc_probs"] is None
+    assert abs(float(loss) - float(g["loss_f64"])) < 1e-4 * float(g["loss_f64"])
+    assert relerr(pts.grad.cpu().numpy(), g["dpoints_f64"]) < 2e-4
+    assert relerr(poses.grad.cpu().numpy(), g["dposes_f64"]) < 2e-4
+    assert relerr(scal.grad.cpu().numpy(), g["dscaling_f64"]) < 2e-4
+
+
+def test_caller_toy_emulated(emu):
+    _check(*_run("cpu"))
+
+
+@pytest.mark.gpu
+def test_caller_toy_gpu():
+    dpc_amd._capi.set_library(None)
+    _check(*_run("cuda"))
+
+
+def test_schedules_match_reference():
+    g = load("caller_toy")
+    cfg = _cfg(g)
+    for s, ref in zip(g["sched_steps"], g["sched_sigma"]):
+        assert abs(M.get_smooth_sigma(cfg, int(s)) - ref) < 1e-6
+    cfg_d = dpc_amd.default_config(pc_point_dropout=0.07)
+    for s, ref in zip(g["sched_steps"], g["sched_drop_lin"]):
+        assert abs(M.get_dropout_prob(cfg_d, int(s)) - ref) < 1e-6
+    cfg_e = dpc_amd.default_config(pc_point_dropout=0.07, pc_point_dropout_exponential_schedule=True)
+    for s, ref in zip(g["sched_steps"], g["sched_drop_exp"]):
+        assert abs(M.get_dropout_prob(cfg_e, int(s)) - ref) < 1e-6
+
+
+def test_tf_repeat_0_and_resize():
+    x = torch.arange(6.0).reshape(3, 2)
+    assert torch.equal(M.tf_repeat_0(x, 2), x[[0, 0, 1, 1, 2, 2]])
+    img = torch.arange(64.0).reshape(1, 8, 8, 1)
+    half = M.resize_images_bilinear_tf1(img, [4, 4])
+    assert torch.equal(half, img[:, ::2, ::2])                  # exact 2x: top-left sample (TF1 legacy)
+    third = M.resize_images_bilinear_tf1(img, [3, 3])
+    assert abs(float(third[0, 1, 1, 0]) - (2.0 + 2.0 / 3) * 9) < 1e-4   # src = 8/3 on both axes -> 9*src
