@@ -503,6 +503,7 @@ k_points_bwd(DpcShape S, DpcParams P, const float* __restrict__ pc, const float*
              const float* __restrict__ tr_pc, const float* __restrict__ dgrid,
              const float* __restrict__ mask, const unsigned char* __restrict__ cmask,
              const float* __restrict__ taps_x, const float* __restrict__ dtr_in /*nullable when GATHER*/,
+             const float* __restrict__ parts /*nullable: [B,N,4,3] from k_gather_yx*/,
              float* __restrict__ dpc, float* __restrict__ accum /*[B,16], zeroed*/) {
   const int b = blockIdx.x;  // view-major block ids: b + B*chunk => one XCD (L2) per view when B % 8 == 0
   const int n = blockIdx.y * blockDim.x + threadIdx.x;
@@ -517,6 +518,15 @@ k_points_bwd(DpcShape S, DpcParams P, const float* __restrict__ pc, const float*
     if (GATHER)
       gather_point<KC>(dgrid, mask, cmask ? cmask + ((size_t)b * S.N + n) * 4 : nullptr, taps_x, S.Kx, b, S.Dz, S.D,
                    tr_pc[o], tr_pc[o + 1], tr_pc[o + 2], dw, dv, du);
+    if (parts) {  // one [3] slot per (corner plane k, corner row j), written by its owning WG
+      const float* pp = parts + ((size_t)b * S.N + n) * 12;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        dw += pp[3 * q];
+        dv += pp[3 * q + 1];
+        du += pp[3 * q + 2];
+      }
+    }
     if (dtr_in) {
       dw += dtr_in[o];
       dv += dtr_in[o + 1];
@@ -1017,6 +1027,130 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
         const int gy = y0 + sy * RS + q - 2 * h;
         if (q >= 2 * h && gy < D) store_cx<VY>(oplane + (size_t)gy * D + ly * VY, o);
       }
+    }
+  }
+}
+
+// Backward counterpart of k_splat_xy.  WG = (view b, plane z, y-strip): stage
+// rows [y0-h, y0+SH+h) of dGz (the z-blurred ray gradients) in LDS, y-blur them
+// into a second LDS tile (register FIR), then, for the points of depth cells
+// z-1 and z (same z-bucketed lists as forward), evaluate the x-blur only at
+// the touched cells, apply the clip-gradient bits and the trilinear weights, and
+// write one [3] partial d(tr_pc) per (corner plane k, corner row j) slot.
+// Replaces the dense y-blur pass (read V + write V) and the scattered global
+// gather by one pass that reads dGz once (+ halo).
+template <int KC, int VY>
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_gather_yx(DpcShape S, const float* __restrict__ dgz, const float* __restrict__ tr_pc,
+            const int* __restrict__ order, const int* __restrict__ zstart,
+            const unsigned char* __restrict__ cmask, const float* __restrict__ taps_x,
+            const float* __restrict__ taps_y, float* __restrict__ parts, int SH, int nstrips) {
+  DPC_DYN_SMEM(float, smem);
+  constexpr int h = KC / 2;
+  constexpr int G = zgroup(KC);
+  const int D = S.D, Dz = S.Dz, N = S.N;
+  const int bid = blockIdx.x;
+  const int strip = bid % nstrips;
+  const int pz = bid / nstrips;
+  const int z = pz % Dz, b = pz / Dz;
+  const int y0 = strip * SH;
+  const int RT = SH + 2 * h;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  float* tin = smem;            // [RT][D]  dGz rows with halo
+  float* ty = smem + RT * D;    // [SH][D]  y-blurred rows
+  const float* plane = dgz + (size_t)pz * D * D;
+
+  // 1. global -> LDS, four 16-byte loads in flight per thread, rows outside the grid are zero
+  const int q4 = D >> 2;  // float4 per row
+  const int total4 = RT * q4;
+  for (int i0 = tid; i0 < total4; i0 += 4 * nth) {
+    float v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * nth;
+      const int ic = i < total4 ? i : total4 - 1;
+      const int t = ic / q4, c4 = ic - t * q4;
+      const int gy = y0 - h + t;
+      const int gyc = gy < 0 ? 0 : (gy >= D ? D - 1 : gy);
+      load_cx<4>(plane + (size_t)gyc * D + c4 * 4, v[u]);
+      if (gy != gyc) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[u][c] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * nth;
+      if (i < total4) store_cx<4>(tin + i * 4, v[u]);
+    }
+  }
+  __syncthreads();
+
+  // 2. y-blur tin -> ty (adjoint of the forward y-blur: same symmetric taps)
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int LRy = D / VY;
+    const int sy = (wave * 64 + lane) / LRy;
+    const int ly = lane & (LRy - 1);
+    const int nsy = nth / LRy;
+    const int RS = SH / nsy;
+    ZFir<KC, VY> fir;
+    fir.init(taps_y);
+    const int steps = RS + 2 * h;
+    for (int q0 = 0; q0 < steps; q0 += G) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int q = q0 + u;
+        if (q < steps) {
+          float v[VY], o[VY];
+          load_cx<VY>(tin + (sy * RS + q) * D + ly * VY, v);
+          fir.push(v, o, u);
+          if (q >= 2 * h) store_cx<VY>(ty + (sy * RS + q - 2 * h) * D + ly * VY, o);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // 3. sparse x-blur + clip bits + trilinear gather for this plane's points
+  const int* zs = zstart + (size_t)b * (Dz + 2);
+  const int lo = zs[z > 0 ? z - 1 : 0], mid = zs[z], hi = zs[z + 1];
+  const float* tp = tr_pc + (size_t)b * N * 3;
+  for (int i = lo + tid; i < hi; i += nth) {
+    const int n = order[(size_t)b * N + i];
+    const int k = (i < mid) ? 1 : 0;
+    const Cell c = locate(tp[3 * n], tp[3 * n + 1], tp[3 * n + 2], Dz, D);
+    const float wzk = k ? c.rz : (1.0f - c.rz);
+    const float wy[2] = {1.0f - c.ry, c.ry};
+    const float wx[2] = {1.0f - c.rx, c.rx};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int yy = c.iy + j;
+      if (yy >= D || yy < y0 || yy >= y0 + SH) continue;
+      const float* row = ty + (yy - y0) * D;
+      float g[2] = {0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m <= KC; ++m) {
+        const int x = c.ix - h + m;
+        const int xc = x < 0 ? 0 : (x >= D ? D - 1 : x);
+        const float val = (x == xc) ? row[xc] : 0.f;
+        if (m < KC) g[0] += taps_x[m] * val;
+        if (m >= 1) g[1] += taps_x[m - 1] * val;
+      }
+      const unsigned bits = cmask[((size_t)b * N + n) * 4 + k * 2 + j];
+      float drz = 0.f, dry = 0.f, drx = 0.f;
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        if (c.ix + l >= D) continue;
+        const float gg = ((bits >> l) & 1u) ? g[l] : 0.f;
+        drz += gg * (k ? 1.f : -1.f) * wy[j] * wx[l];
+        dry += gg * wzk * (j ? 1.f : -1.f) * wx[l];
+        drx += gg * wzk * wy[j] * (l ? 1.f : -1.f);
+      }
+      float* pp = parts + (((size_t)b * N + n) * 4 + k * 2 + j) * 3;
+      pp[0] = drz * (float)(Dz - 1);
+      pp[1] = dry * (float)(D - 1);
+      pp[2] = drx * (float)(D - 1);
     }
   }
 }
@@ -1627,8 +1761,8 @@ int launch_zbwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const flo
 int launch_points_bwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const float* pc,
                       const float* pose, const float* trans, const float* focal, const float* tr_pc,
                       const float* dgrid, const float* mask, const unsigned char* cmask, const float* taps_x,
-                      const float* dtr_in, bool gather, float* dpc, float* dpose, float* dtrans, float* dfocal,
-                      float* dscale, float* accum, bool zero_accum) {
+                      const float* dtr_in, const float* parts, bool gather, float* dpc, float* dpose,
+                      float* dtrans, float* dfocal, float* dscale, float* accum, bool zero_accum) {
   if (zero_accum) {
     hipError_t e = dpc_memset("memset_small", accum, sizeof(float) * 16 * (size_t)S.B, st);
     if (e != hipSuccess) return (int)e;
@@ -1637,7 +1771,7 @@ int launch_points_bwd(hipStream_t st, const DpcShape& S, const DpcParams& P, con
   const bool quat = P.pose_is_quaternion != 0;
 #define DPC_PB(Q, G, KC)                                                                              \
   DPC_LAUNCH("points_bwd", (k_points_bwd<Q, G, KC>), grid, block, 0, st, S, P, pc, pose, trans, focal, tr_pc, dgrid, \
-             mask, cmask, taps_x, dtr_in, dpc, accum)
+             mask, cmask, taps_x, dtr_in, parts, dpc, accum)
   const int kc = (gather && (S.Kx == 5 || S.Kx == 11 || S.Kx == 21)) ? S.Kx : 0;
   if (quat && gather) {
     if (kc == 11) DPC_PB(true, true, 11);
@@ -1667,9 +1801,11 @@ struct SplatPlan {
   bool ok;
   int SH, nstrips, lr_shift, vy;
   size_t lds_bytes;
+  int gSH, gstrips;  // k_gather_yx strips (two LDS tiles)
+  size_t glds_bytes;
 };
 SplatPlan splat_plan(const DpcShape& S) {
-  SplatPlan p = {false, 0, 0, 0, 0, 0};
+  SplatPlan p = {false, 0, 0, 0, 0, 0, 0, 0, 0};
   const int D = S.D, K = S.Kx;
   if (S.Kx != S.Ky || (K != 5 && K != 11 && K != 21)) return p;
   if (D < 32 || D > 256 || (D & (D - 1)) != 0 || S.N <= 0) return p;
@@ -1682,6 +1818,12 @@ SplatPlan splat_plan(const DpcShape& S) {
   p.vy = (D <= 128) ? 2 : 4;              // y-phase floats per lane (k_splat_xy step 5)
   const int nsy = DPC_BLOCK / (D / p.vy);
   if (nsy < 1 || SH % nsy != 0) return p;
+  int gSH = D;
+  while (gSH >= nsy && sizeof(float) * (size_t)(2 * gSH + 2 * (K / 2)) * D > 48 * 1024) gSH >>= 1;
+  if (gSH < nsy || gSH % nsy != 0) return p;
+  p.gSH = gSH;
+  p.gstrips = D / gSH;
+  p.glds_bytes = sizeof(float) * (size_t)(2 * gSH + 2 * (K / 2)) * D;
   p.ok = true;
   p.SH = SH;
   p.nstrips = D / SH;
@@ -1689,8 +1831,31 @@ SplatPlan splat_plan(const DpcShape& S) {
   p.lds_bytes = sizeof(float) * (size_t)(SH + 2 * (K / 2)) * D;
   return p;
 }
-inline size_t splat_index_bytes(const DpcShape& S) {
-  return align256(sizeof(int) * (size_t)S.B * S.N) + align256(sizeof(int) * (size_t)S.B * (S.Dz + 2));
+inline size_t point_index_ints(const DpcShape& S) { return (size_t)S.B * S.N + (size_t)S.B * (S.Dz + 2); }
+inline size_t parts_bytes(const DpcShape& S) { return align256(sizeof(float) * 12 * (size_t)S.B * S.N); }
+
+int launch_gather_yx(hipStream_t st, const DpcShape& S, const SplatPlan& pl, const float* dgz, const float* tr_pc,
+                     const int* order, const int* zstart, const unsigned char* cmask, const float* tx,
+                     const float* ty, float* parts) {
+  hipError_t e = dpc_memset("memset_parts", parts, sizeof(float) * 12 * (size_t)S.B * S.N, st);
+  if (e != hipSuccess) return (int)e;
+  const long long nblk = (long long)S.B * S.Dz * pl.gstrips;
+  if (nblk > 0x7fffffffLL) return DPC_E_SHAPE;
+  const dim3 grid((unsigned)nblk, 1, 1), block(DPC_BLOCK, 1, 1);
+#define DPC_GY(KC, VY)                                                                                       \
+  DPC_LAUNCH("gather_yx", (k_gather_yx<KC, VY>), grid, block, pl.glds_bytes, st, S, dgz, tr_pc, order, zstart, \
+             cmask, tx, ty, parts, pl.gSH, pl.gstrips)
+#define DPC_GYV(KC)                \
+  do {                             \
+    if (pl.vy == 2) DPC_GY(KC, 2); \
+    else DPC_GY(KC, 4);            \
+  } while (0)
+  if (S.Kx == 5) DPC_GYV(5);
+  else if (S.Kx == 11) DPC_GYV(11);
+  else DPC_GYV(21);
+#undef DPC_GYV
+#undef DPC_GY
+  return last_error();
 }
 
 int launch_splat_xy(hipStream_t st, const DpcShape& S, const SplatPlan& pl, const float* tr_pc, int* order,
@@ -1733,7 +1898,7 @@ int dpc_profile_enable(int on) {
 
 int dpc_saved_layout(const DpcShape* shape, const DpcParams* params) {
   if (check_shape(shape, true) != DPC_OK || !params) return DPC_E_SHAPE;
-  return splat_plan(*shape).ok ? 2 : 1;  // bit 0: grid_raw, bit 1: clip_mask
+  return splat_plan(*shape).ok ? 6 : 1;  // bit 0: grid_raw; bits 1+2: clip_mask + point_index
 }
 
 int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, int width) {
@@ -1776,7 +1941,7 @@ size_t dpc_workspace_bytes(const DpcShape* shape, int direction) {
   if (check_shape(shape, false) != DPC_OK) return 0;
   const size_t g = align256(grid_elems(*shape) * sizeof(float));
   const size_t acc = align256(sizeof(float) * 16 * (size_t)shape->B);
-  return direction == 0 ? g + splat_index_bytes(*shape) : 2 * g + acc;
+  return direction == 0 ? g : 2 * g + acc + parts_bytes(*shape);
 }
 
 int dpc_transform_fwd(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* pc,
@@ -1804,7 +1969,8 @@ int dpc_transform_bwd(dpc_stream_t stream, const DpcShape* shape, const DpcParam
   if (!params || !pc || !pose || !dtr_pc || !dpc || !dpose || !scratch) return DPC_E_NULL;
   if (!params->pose_is_quaternion && trans) return DPC_E_MODE;
   return launch_points_bwd((hipStream_t)stream, *shape, *params, pc, pose, trans, focal, nullptr, nullptr,
-                           nullptr, nullptr, nullptr, dtr_pc, false, dpc, dpose, dtrans, dfocal, nullptr, scratch, true);
+                           nullptr, nullptr, nullptr, dtr_pc, nullptr, false, dpc, dpose, dtrans, dfocal, nullptr,
+                           scratch, true);
 }
 
 int dpc_voxelize_fwd(dpc_stream_t stream, const DpcShape* shape, const float* tr_pc, float* grid) {
@@ -1894,8 +2060,9 @@ int dpc_max_collapse_bwd(dpc_stream_t stream, const DpcShape* shape, const float
 int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* pc,
                         const float* pose, const float* trans, const float* scale, const float* focal,
                         const float* taps_x, const float* taps_y, const float* taps_z, float* tr_pc,
-                        float* grid_raw, unsigned char* clip_mask, float* grid_blur, double* ray_sums,
-                        float* proj, float* proj_depth, void* workspace, size_t workspace_bytes) {
+                        float* grid_raw, unsigned char* clip_mask, int32_t* point_index, float* grid_blur,
+                        double* ray_sums, float* proj, float* proj_depth, void* workspace,
+                        size_t workspace_bytes) {
   int rc = check_shape(shape, true);
   if (rc) return rc;
   if (!params || !pc || !pose || !tr_pc || !grid_blur || !proj) return DPC_E_NULL;
@@ -1907,7 +2074,7 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   if (!drc && P.collapse_mode != DPC_COLLAPSE_MAX) return DPC_E_MODE;
   if (drc && !ray_sums) return DPC_E_NULL;
   const SplatPlan plan = splat_plan(S);
-  if (plan.ok ? !clip_mask : !grid_raw) return DPC_E_NULL;
+  if (plan.ok ? (!clip_mask || !point_index) : !grid_raw) return DPC_E_NULL;
   const bool plane = S.Kx > 0 || S.Ky > 0;
   if (plane && (!workspace || workspace_bytes < dpc_workspace_bytes(shape, 0) ||
                 ((uintptr_t)workspace & 255) != 0))
@@ -1928,9 +2095,8 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
                  (float*)nullptr);
     rc = last_error();
     if (rc) return rc;
-    char* ws = (char*)workspace + align256(grid_elems(S) * sizeof(float));
-    int* order = (int*)ws;
-    int* zstart = (int*)(ws + align256(sizeof(int) * (size_t)S.B * S.N));
+    int* order = (int*)point_index;                  // [B,N]   points sorted by depth cell
+    int* zstart = order + (size_t)S.B * S.N;         // [B,Dz+2] bucket starts
     rc = launch_splat_xy(st, S, plan, tr_pc, order, zstart, taps_x, taps_y, tmp, clip_mask);
     if (rc) return rc;
     zin = tmp;
@@ -1984,8 +2150,9 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
 int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* pc,
                          const float* pose, const float* trans, const float* scale, const float* focal,
                          const float* taps_x, const float* taps_y, const float* taps_z, const float* tr_pc,
-                         const float* grid_raw, const unsigned char* clip_mask, const float* grid_blur,
-                         const double* ray_sums, const float* dproj, const float* dproj_depth,
+                         const float* grid_raw, const unsigned char* clip_mask, const int32_t* point_index,
+                         const float* grid_blur, const double* ray_sums, const float* dproj,
+                         const float* dproj_depth,
                          const float* dtr_pc_in, float* dpc, float* dpose, float* dtrans, float* dscale,
                          float* dfocal, void* workspace, size_t workspace_bytes) {
   int rc = check_shape(shape, true);
@@ -1999,8 +2166,9 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   if (!drc && P.collapse_mode != DPC_COLLAPSE_MAX) return DPC_E_MODE;
   if (!dproj && !(drc && dproj_depth)) return DPC_E_NULL;
   if (scale && !dscale) return DPC_E_NULL;
-  const bool use_cmask = splat_plan(S).ok;
-  if (use_cmask ? !clip_mask : !grid_raw) return DPC_E_NULL;
+  const SplatPlan plan = splat_plan(S);
+  const bool use_cmask = plan.ok;
+  if (use_cmask ? (!clip_mask || !point_index) : !grid_raw) return DPC_E_NULL;
   if (!workspace || workspace_bytes < dpc_workspace_bytes(shape, 1) || ((uintptr_t)workspace & 255) != 0)
     return DPC_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -2008,6 +2176,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   float* tA = (float*)workspace;
   float* tB = (float*)((char*)workspace + gbytes);
   float* accum = (float*)((char*)workspace + 2 * gbytes);  // [B,16]: pose/trans/focal sums, slot 15 = dscale
+  float* parts = (float*)((char*)accum + align256(sizeof(float) * 16 * (size_t)S.B));  // [B,N,4,3]
 
   hipError_t e = dpc_memset("memset_small", accum, sizeof(float) * 16 * (size_t)S.B, st);
   if (e != hipSuccess) return (int)e;
@@ -2033,6 +2202,17 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
       if (rc) return rc;
     }
   }
+  if (use_cmask) {
+    // 2+3 fused: per-plane LDS pass (y-blur + sparse x-blur + clip bits + trilinear gather),
+    // then the camera-transform VJP over the per-corner partials
+    const int* order = (const int*)point_index;
+    const int* zstart = order + (size_t)S.B * S.N;
+    rc = launch_gather_yx(st, S, plan, tA, tr_pc, order, zstart, clip_mask, taps_x, taps_y, parts);
+    if (rc) return rc;
+    return launch_points_bwd(st, S, P, pc, pose, trans, focal, tr_pc, nullptr, nullptr, nullptr, nullptr,
+                             dtr_pc_in, parts, false, dpc, dpose, dtrans, dfocal, scale ? dscale : nullptr,
+                             accum, false);
+  }
   // 2. y-blur adjoint (dense) -> tB ; the x-blur is evaluated sparsely in step 3
   const float* dg = tA;
   if (S.Ky > 0) {
@@ -2041,9 +2221,8 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
     dg = tB;
   }
   // 3. sparse x-blur + clip mask + gather + transform VJP + reductions
-  return launch_points_bwd(st, S, P, pc, pose, trans, focal, tr_pc, dg, use_cmask ? nullptr : grid_raw,
-                           use_cmask ? clip_mask : nullptr, taps_x, dtr_pc_in, true, dpc, dpose, dtrans, dfocal,
-                           scale ? dscale : nullptr, accum, false);
+  return launch_points_bwd(st, S, P, pc, pose, trans, focal, tr_pc, dg, grid_raw, nullptr, taps_x, dtr_pc_in,
+                           nullptr, true, dpc, dpose, dtrans, dfocal, scale ? dscale : nullptr, accum, false);
 }
 
 }  // extern "C"

@@ -136,6 +136,7 @@ class ProjectFused(torch.autograd.Function):
         lib.check(min(layout, 0), "dpc_saved_layout")
         grid_raw = new(B, Dz, D, D) if layout & 1 else None
         clip_mask = new(B, N, 4, dtype=torch.uint8) if layout & 2 else None
+        point_index = new(B * N + B * (Dz + 2), dtype=torch.int32) if layout & 4 else None
         grid_blur = new(B, Dz, D, D)
         drc = meta.collapse_mode == _capi.DPC_COLLAPSE_DRC
         logt = new(B, D, D, 2, dtype=torch.float64) if drc else None
@@ -145,19 +146,20 @@ class ProjectFused(torch.autograd.Function):
         rc = lib.dpc_project_forward(_stream(lib, pc), ctypes.byref(shape), ctypes.byref(params),
                                      _p(pc), _p(pose), _p(trans), _p(scale), _p(focal),
                                      _p(tx), _p(ty), _p(tz), _p(tr_pc), _p(grid_raw), _p(clip_mask),
-                                     _p(grid_blur), _p(logt), _p(proj), _p(depth), ws.ptr, ws.nbytes)
+                                     _p(point_index), _p(grid_blur), _p(logt), _p(proj), _p(depth), ws.ptr, ws.nbytes)
         lib.check(rc, "dpc_project_forward")
         ctx.meta, ctx.K = meta, K
         ctx.has = (trans is not None, scale is not None, focal is not None)
         ctx.scale_shape = None if scale is None else tuple(scale.shape)
         ctx.focal_shape = None if focal is None else tuple(focal.shape)
-        ctx.save_for_backward(pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, grid_raw, clip_mask, grid_blur,
-                              logt)
+        ctx.save_for_backward(pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, grid_raw, clip_mask, point_index,
+                              grid_blur, logt)
         return proj, depth, tr_pc
 
     @staticmethod
     def backward(ctx, dproj, ddepth, dtr):
-        pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, grid_raw, clip_mask, grid_blur, logt = ctx.saved_tensors
+        (pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, grid_raw, clip_mask, point_index, grid_blur,
+         logt) = ctx.saved_tensors
         meta = ctx.meta
         lib = _lib_for(pc)
         B, N = pc.shape[0], pc.shape[1]
@@ -179,7 +181,7 @@ class ProjectFused(torch.autograd.Function):
         rc = lib.dpc_project_backward(_stream(lib, pc), ctypes.byref(shape), ctypes.byref(params),
                                       _p(pc), _p(pose), _p(trans), _p(scale), _p(focal),
                                       _p(tx), _p(ty), _p(tz), _p(tr_pc), _p(grid_raw), _p(clip_mask),
-                                      _p(grid_blur), _p(logt), _p(dproj), _p(ddepth), _p(dtr),
+                                      _p(point_index), _p(grid_blur), _p(logt), _p(dproj), _p(ddepth), _p(dtr),
                                       _p(dpc), _p(dpose), _p(dtrans), _p(dscale), _p(dfocal),
                                       ws.ptr, ws.nbytes)
         lib.check(rc, "dpc_project_backward")

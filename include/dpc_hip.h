@@ -84,7 +84,10 @@ int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, 
  * (generic path: zero-fill + global float atomics); bit 1 (value 2) = clip_mask
  * [B,N,4] bytes, one bit per touched trilinear corner (fused path: points are
  * bucketed by depth cell and splatted into per-plane LDS tiles, the raw grid
- * never reaches HBM).  The buffer that is not used may be null.  <0 on error. */
+ * never reaches HBM); bit 2 (value 4) = point_index, int32 [B*N + B*(Dz+2)]: the
+ * points of each view sorted by depth cell followed by the bucket starts, which
+ * the backward's per-plane gather re-uses (set together with bit 1).  Buffers
+ * that are not used may be null.  <0 on error. */
 int dpc_saved_layout(const DpcShape* shape, const DpcParams* params);
 
 /* Bytes of scratch `dpc_project_forward` (direction 0) / `dpc_project_backward`
@@ -99,7 +102,7 @@ size_t dpc_workspace_bytes(const DpcShape* shape, int direction);
  *   -> drc_projection / reduce_max (drc.py:110-123 / :264-267)
  *   -> drc_depth_projection (drc.py:146-153) -> flips (:270,273).
  * Saved for backward (caller-owned): tr_pc [B,N,3], grid_raw [B,Dz,D,D]
- * (pre-clip scatter) OR clip_mask [B,N,4] bytes (see dpc_saved_layout),
+ * (pre-clip scatter) OR clip_mask [B,N,4] bytes + point_index (see dpc_saved_layout),
  * grid_blur [B,Dz,D,D] (post-blur, pre-scale),
  * ray_sums [B,D,D,2] float64 (per ray, grid-row order: sum_{j<Dz} p_j and
  * sum_{j<=Dz} p_j psi_j of the event probabilities, needed by the backward).
@@ -108,8 +111,8 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
                         const float* pc, const float* pose, const float* trans /*[B,3]|null*/,
                         const float* scale /*[B]|null*/, const float* focal /*[B]|null*/,
                         const float* taps_x, const float* taps_y, const float* taps_z,
-                        float* tr_pc, float* grid_raw, unsigned char* clip_mask, float* grid_blur,
-                        double* ray_sums, float* proj, float* proj_depth /*null for MAX*/,
+                        float* tr_pc, float* grid_raw, unsigned char* clip_mask, int32_t* point_index,
+                        float* grid_blur, double* ray_sums, float* proj, float* proj_depth /*null for MAX*/,
                         void* workspace, size_t workspace_bytes);
 
 /* Backward of the above = what TF autodiff builds for
@@ -123,7 +126,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
                          const float* scale, const float* focal,
                          const float* taps_x, const float* taps_y, const float* taps_z,
                          const float* tr_pc, const float* grid_raw, const unsigned char* clip_mask,
-                         const float* grid_blur, const double* ray_sums,
+                         const int32_t* point_index, const float* grid_blur, const double* ray_sums,
                          const float* dproj, const float* dproj_depth, const float* dtr_pc_in,
                          float* dpc, float* dpose, float* dtrans, float* dscale, float* dfocal,
                          void* workspace, size_t workspace_bytes);

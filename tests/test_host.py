@@ -55,10 +55,10 @@ def test_c_abi_argument_validation_without_gpu():
     assert lib.dpc_workspace_bytes(ctypes.byref(S), 0) % 256 == 0
     assert lib.dpc_saved_layout(ctypes.byref(S), ctypes.byref(P)) == 1      # D=8: generic path, dense grid_raw
     S64 = _capi.DpcShape(2, 10, 64, 64, 11, 11, 11)
-    assert lib.dpc_saved_layout(ctypes.byref(S64), ctypes.byref(P)) == 2    # fused splat path, clip_mask bytes
+    assert lib.dpc_saved_layout(ctypes.byref(S64), ctypes.byref(P)) == 6    # fused path: clip_mask + point_index
     assert lib.dpc_workspace_bytes(ctypes.byref(S), 1) >= 2 * g
     null = None
-    rc = lib.dpc_project_forward(null, ctypes.byref(S), ctypes.byref(P), *([null] * 15), null, 0)
+    rc = lib.dpc_project_forward(null, ctypes.byref(S), ctypes.byref(P), *([null] * 16), null, 0)
     assert rc == -1                                      # DPC_E_NULL
     rc = lib.dpc_voxelize_fwd(null, ctypes.byref(_capi.DpcShape(0, 1, 8, 8, 0, 0, 0)), null, null)
     assert rc == -2                                      # DPC_E_SHAPE
