@@ -1031,127 +1031,142 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
   }
 }
 
-// Backward counterpart of k_splat_xy.  WG = (view b, plane z, y-strip): stage
-// rows [y0-h, y0+SH+h) of dGz (the z-blurred ray gradients) in LDS, y-blur them
-// into a second LDS tile (register FIR), then, for the points of depth cells
-// z-1 and z (same z-bucketed lists as forward), evaluate the x-blur only at
-// the touched cells, apply the clip-gradient bits and the trilinear weights, and
-// write one [3] partial d(tr_pc) per (corner plane k, corner row j) slot.
-// Replaces the dense y-blur pass (read V + write V) and the scattered global
-// gather by one pass that reads dGz once (+ halo).
-template <int KC, int VY>
+// Backward counterpart of k_splat_xy.  WG = (view b, PZ consecutive planes,
+// y-strip).  Per plane: stage rows [y0-h, y0+SH+h) of dGz (the z-blurred ray
+// gradients) in LDS, y-blur them in place (register FIR, outputs parked in
+// registers across a barrier), then, for the points of depth cells z-1 and z
+// (same z-bucketed lists as forward), evaluate the x-blur only at the touched
+// cells, apply the clip-gradient bits and the trilinear weights, and write one
+// [3] partial d(tr_pc) per (corner plane k, corner row j) slot.  The next
+// plane's rows are already in flight in registers while the current plane is
+// processed.  Replaces the dense y-blur pass (read V + write V) and the
+// scattered global gather by one pass that reads dGz once (+ halo).
+#define DPC_GATHER_PZ 4
+template <int KC, int VY, int RS>
 __global__ void __launch_bounds__(DPC_BLOCK)
 k_gather_yx(DpcShape S, const float* __restrict__ dgz, const float* __restrict__ tr_pc,
             const int* __restrict__ order, const int* __restrict__ zstart,
             const unsigned char* __restrict__ cmask, const float* __restrict__ taps_x,
             const float* __restrict__ taps_y, float* __restrict__ parts, int SH, int nstrips) {
-  DPC_DYN_SMEM(float, smem);
+  DPC_DYN_SMEM(float, tin);  // [RT][D]
   constexpr int h = KC / 2;
-  constexpr int G = zgroup(KC);
+  constexpr int NLD = 10;    // 16-byte loads per thread and plane (host guarantees RT*D/4 <= NLD*256)
   const int D = S.D, Dz = S.Dz, N = S.N;
+  const int nzg = (Dz + DPC_GATHER_PZ - 1) / DPC_GATHER_PZ;
   const int bid = blockIdx.x;
   const int strip = bid % nstrips;
-  const int pz = bid / nstrips;
-  const int z = pz % Dz, b = pz / Dz;
+  const int zg = (bid / nstrips) % nzg;
+  const int b = bid / (nstrips * nzg);
   const int y0 = strip * SH;
   const int RT = SH + 2 * h;
   const int tid = threadIdx.x, nth = blockDim.x;
-  float* tin = smem;            // [RT][D]  dGz rows with halo
-  float* ty = smem + RT * D;    // [SH][D]  y-blurred rows
-  const float* plane = dgz + (size_t)pz * D * D;
-
-  // 1. global -> LDS, four 16-byte loads in flight per thread, rows outside the grid are zero
   const int q4 = D >> 2;  // float4 per row
   const int total4 = RT * q4;
-  for (int i0 = tid; i0 < total4; i0 += 4 * nth) {
-    float v[4][4];
+  const int lane = tid & 63, wave = tid >> 6;
+  const int LRy = D / VY;
+  const int sy = (wave * 64 + lane) / LRy;
+  const int ly = lane & (LRy - 1);
+  const int* zs = zstart + (size_t)b * (Dz + 2);
+  const float* tp = tr_pc + (size_t)b * N * 3;
+  float tpx[KC + 1];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * nth;
+  for (int m = 0; m < KC; ++m) tpx[m] = taps_x[m];
+
+  float pre[NLD][4];
+  auto prefetch = [&](int z) {  // rows of plane z -> registers (unconditional, clamped; zeroed at store time)
+    const float* plane = dgz + ((size_t)b * Dz + (z < Dz ? z : Dz - 1)) * D * D;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int i = tid + u * nth;
       const int ic = i < total4 ? i : total4 - 1;
       const int t = ic / q4, c4 = ic - t * q4;
       const int gy = y0 - h + t;
       const int gyc = gy < 0 ? 0 : (gy >= D ? D - 1 : gy);
-      load_cx<4>(plane + (size_t)gyc * D + c4 * 4, v[u]);
-      if (gy != gyc) {
+      load_cx<4>(plane + (size_t)gyc * D + c4 * 4, pre[u]);
+    }
+  };
+  const int zbeg = zg * DPC_GATHER_PZ;
+  prefetch(zbeg);
+  for (int zi = 0; zi < DPC_GATHER_PZ; ++zi) {
+    const int z = zbeg + zi;
+    if (z >= Dz) break;  // uniform
+    // 1. registers -> LDS (rows outside the grid are zero)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[u][c] = 0.f;
+    for (int u = 0; u < NLD; ++u) {
+      const int i = tid + u * nth;
+      if (i < total4) {
+        const int t = i / q4;
+        const int gy = y0 - h + t;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = (gy >= 0 && gy < D) ? pre[u][c] : 0.f;
+        store_cx<4>(tin + i * 4, v);
       }
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * nth;
-      if (i < total4) store_cx<4>(tin + i * 4, v[u]);
-    }
-  }
-  __syncthreads();
+    __syncthreads();
+    if (zi + 1 < DPC_GATHER_PZ) prefetch(z + 1);  // in flight during steps 2-3
 
-  // 2. y-blur tin -> ty (adjoint of the forward y-blur: same symmetric taps)
-  {
-    const int lane = tid & 63, wave = tid >> 6;
-    const int LRy = D / VY;
-    const int sy = (wave * 64 + lane) / LRy;
-    const int ly = lane & (LRy - 1);
-    const int nsy = nth / LRy;
-    const int RS = SH / nsy;
-    ZFir<KC, VY> fir;
-    fir.init(taps_y);
-    const int steps = RS + 2 * h;
-    for (int q0 = 0; q0 < steps; q0 += G) {
+    // 2. y-blur (adjoint of the forward y-blur: same symmetric taps), outputs in registers
+    float outr[RS][VY];
+    {
+      ZFir<KC, VY> fir;
+      fir.init(taps_y);
 #pragma unroll
-      for (int u = 0; u < G; ++u) {
-        const int q = q0 + u;
-        if (q < steps) {
-          float v[VY], o[VY];
-          load_cx<VY>(tin + (sy * RS + q) * D + ly * VY, v);
-          fir.push(v, o, u);
-          if (q >= 2 * h) store_cx<VY>(ty + (sy * RS + q - 2 * h) * D + ly * VY, o);
+      for (int q = 0; q < RS + 2 * h; ++q) {
+        float v[VY], o[VY];
+        load_cx<VY>(tin + (sy * RS + q) * D + ly * VY, v);
+        fir.push(v, o, q);
+        if (q >= 2 * h) {
+#pragma unroll
+          for (int c = 0; c < VY; ++c) outr[q - 2 * h][c] = o[c];
         }
       }
     }
-  }
-  __syncthreads();
+    __syncthreads();  // every stream has read its rows: overwrite rows [h, h+SH) with the blurred ones
+#pragma unroll
+    for (int r = 0; r < RS; ++r) store_cx<VY>(tin + (h + sy * RS + r) * D + ly * VY, outr[r]);
+    __syncthreads();
 
-  // 3. sparse x-blur + clip bits + trilinear gather for this plane's points
-  const int* zs = zstart + (size_t)b * (Dz + 2);
-  const int lo = zs[z > 0 ? z - 1 : 0], mid = zs[z], hi = zs[z + 1];
-  const float* tp = tr_pc + (size_t)b * N * 3;
-  for (int i = lo + tid; i < hi; i += nth) {
-    const int n = order[(size_t)b * N + i];
-    const int k = (i < mid) ? 1 : 0;
-    const Cell c = locate(tp[3 * n], tp[3 * n + 1], tp[3 * n + 2], Dz, D);
-    const float wzk = k ? c.rz : (1.0f - c.rz);
-    const float wy[2] = {1.0f - c.ry, c.ry};
-    const float wx[2] = {1.0f - c.rx, c.rx};
+    // 3. sparse x-blur + clip bits + trilinear gather for this plane's points
+    const int lo = zs[z > 0 ? z - 1 : 0], mid = zs[z], hi = zs[z + 1];
+    for (int i = lo + tid; i < hi; i += nth) {
+      const int n = order[(size_t)b * N + i];
+      const int k = (i < mid) ? 1 : 0;
+      const Cell c = locate(tp[3 * n], tp[3 * n + 1], tp[3 * n + 2], Dz, D);
+      const float wzk = k ? c.rz : (1.0f - c.rz);
+      const float wy[2] = {1.0f - c.ry, c.ry};
+      const float wx[2] = {1.0f - c.rx, c.rx};
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int yy = c.iy + j;
-      if (yy >= D || yy < y0 || yy >= y0 + SH) continue;
-      const float* row = ty + (yy - y0) * D;
-      float g[2] = {0.f, 0.f};
+      for (int j = 0; j < 2; ++j) {
+        const int yy = c.iy + j;
+        if (yy >= D || yy < y0 || yy >= y0 + SH) continue;
+        const float* row = tin + (h + yy - y0) * D;
+        float g[2] = {0.f, 0.f};
 #pragma unroll
-      for (int m = 0; m <= KC; ++m) {
-        const int x = c.ix - h + m;
-        const int xc = x < 0 ? 0 : (x >= D ? D - 1 : x);
-        const float val = (x == xc) ? row[xc] : 0.f;
-        if (m < KC) g[0] += taps_x[m] * val;
-        if (m >= 1) g[1] += taps_x[m - 1] * val;
+        for (int m = 0; m <= KC; ++m) {
+          const int x = c.ix - h + m;
+          const int xc = x < 0 ? 0 : (x >= D ? D - 1 : x);
+          const float val = (x == xc) ? row[xc] : 0.f;
+          if (m < KC) g[0] += tpx[m] * val;
+          if (m >= 1) g[1] += tpx[m - 1] * val;
+        }
+        const unsigned bits = cmask[((size_t)b * N + n) * 4 + k * 2 + j];
+        float drz = 0.f, dry = 0.f, drx = 0.f;
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+          if (c.ix + l >= D) continue;
+          const float gg = ((bits >> l) & 1u) ? g[l] : 0.f;
+          drz += gg * (k ? 1.f : -1.f) * wy[j] * wx[l];
+          dry += gg * wzk * (j ? 1.f : -1.f) * wx[l];
+          drx += gg * wzk * wy[j] * (l ? 1.f : -1.f);
+        }
+        float* pp = parts + (((size_t)b * N + n) * 4 + k * 2 + j) * 3;
+        pp[0] = drz * (float)(Dz - 1);
+        pp[1] = dry * (float)(D - 1);
+        pp[2] = drx * (float)(D - 1);
       }
-      const unsigned bits = cmask[((size_t)b * N + n) * 4 + k * 2 + j];
-      float drz = 0.f, dry = 0.f, drx = 0.f;
-#pragma unroll
-      for (int l = 0; l < 2; ++l) {
-        if (c.ix + l >= D) continue;
-        const float gg = ((bits >> l) & 1u) ? g[l] : 0.f;
-        drz += gg * (k ? 1.f : -1.f) * wy[j] * wx[l];
-        dry += gg * wzk * (j ? 1.f : -1.f) * wx[l];
-        drx += gg * wzk * wy[j] * (l ? 1.f : -1.f);
-      }
-      float* pp = parts + (((size_t)b * N + n) * 4 + k * 2 + j) * 3;
-      pp[0] = drz * (float)(Dz - 1);
-      pp[1] = dry * (float)(D - 1);
-      pp[2] = drx * (float)(D - 1);
     }
+    __syncthreads();  // the tile is refilled by the next plane
   }
 }
 
@@ -1801,11 +1816,11 @@ struct SplatPlan {
   bool ok;
   int SH, nstrips, lr_shift, vy;
   size_t lds_bytes;
-  int gSH, gstrips;  // k_gather_yx strips (two LDS tiles)
+  int gSH, gRS, gstrips;  // k_gather_yx strips (gSH == 0: not applicable)
   size_t glds_bytes;
 };
 SplatPlan splat_plan(const DpcShape& S) {
-  SplatPlan p = {false, 0, 0, 0, 0, 0, 0, 0, 0};
+  SplatPlan p = {false, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int D = S.D, K = S.Kx;
   if (S.Kx != S.Ky || (K != 5 && K != 11 && K != 21)) return p;
   if (D < 32 || D > 256 || (D & (D - 1)) != 0 || S.N <= 0) return p;
@@ -1818,12 +1833,23 @@ SplatPlan splat_plan(const DpcShape& S) {
   p.vy = (D <= 128) ? 2 : 4;              // y-phase floats per lane (k_splat_xy step 5)
   const int nsy = DPC_BLOCK / (D / p.vy);
   if (nsy < 1 || SH % nsy != 0) return p;
-  int gSH = D;
-  while (gSH >= nsy && sizeof(float) * (size_t)(2 * gSH + 2 * (K / 2)) * D > 48 * 1024) gSH >>= 1;
-  if (gSH < nsy || gSH % nsy != 0) return p;
-  p.gSH = gSH;
-  p.gstrips = D / gSH;
-  p.glds_bytes = sizeof(float) * (size_t)(2 * gSH + 2 * (K / 2)) * D;
+  // k_gather_yx: one LDS tile of gSH + 2h rows, gRS = gSH / nsy rows per y-stream in {16, 8},
+  // at most 10 16-byte loads per thread and plane; otherwise backward uses the generic kernels
+  p.gSH = 0;
+  for (int rs = 16; rs >= 8; rs >>= 1) {
+    const int g = rs * nsy;
+    if (g > D) continue;
+    const size_t rows = (size_t)g + 2 * (K / 2);
+    if (sizeof(float) * rows * D <= 48 * 1024 && rows * (D / 4) <= 10 * DPC_BLOCK) {
+      p.gSH = g;
+      p.gRS = rs;
+      break;
+    }
+  }
+  if (p.gSH > 0) {
+    p.gstrips = D / p.gSH;
+    p.glds_bytes = sizeof(float) * (size_t)(p.gSH + 2 * (K / 2)) * D;
+  }
   p.ok = true;
   p.SH = SH;
   p.nstrips = D / SH;
@@ -1839,16 +1865,19 @@ int launch_gather_yx(hipStream_t st, const DpcShape& S, const SplatPlan& pl, con
                      const float* ty, float* parts) {
   hipError_t e = dpc_memset("memset_parts", parts, sizeof(float) * 12 * (size_t)S.B * S.N, st);
   if (e != hipSuccess) return (int)e;
-  const long long nblk = (long long)S.B * S.Dz * pl.gstrips;
+  const int nzg = (S.Dz + DPC_GATHER_PZ - 1) / DPC_GATHER_PZ;
+  const long long nblk = (long long)S.B * nzg * pl.gstrips;
   if (nblk > 0x7fffffffLL) return DPC_E_SHAPE;
   const dim3 grid((unsigned)nblk, 1, 1), block(DPC_BLOCK, 1, 1);
-#define DPC_GY(KC, VY)                                                                                       \
-  DPC_LAUNCH("gather_yx", (k_gather_yx<KC, VY>), grid, block, pl.glds_bytes, st, S, dgz, tr_pc, order, zstart, \
-             cmask, tx, ty, parts, pl.gSH, pl.gstrips)
-#define DPC_GYV(KC)                \
-  do {                             \
-    if (pl.vy == 2) DPC_GY(KC, 2); \
-    else DPC_GY(KC, 4);            \
+#define DPC_GY(KC, VY, RS)                                                                                   \
+  DPC_LAUNCH("gather_yx", (k_gather_yx<KC, VY, RS>), grid, block, pl.glds_bytes, st, S, dgz, tr_pc, order,  \
+             zstart, cmask, tx, ty, parts, pl.gSH, pl.gstrips)
+#define DPC_GYV(KC)                                      \
+  do {                                                   \
+    if (pl.vy == 2 && pl.gRS == 16) DPC_GY(KC, 2, 16);   \
+    else if (pl.vy == 2) DPC_GY(KC, 2, 8);               \
+    else if (pl.gRS == 16) DPC_GY(KC, 4, 16);            \
+    else DPC_GY(KC, 4, 8);                               \
   } while (0)
   if (S.Kx == 5) DPC_GYV(5);
   else if (S.Kx == 11) DPC_GYV(11);
@@ -2202,7 +2231,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
       if (rc) return rc;
     }
   }
-  if (use_cmask) {
+  if (use_cmask && plan.gSH > 0) {
     // 2+3 fused: per-plane LDS pass (y-blur + sparse x-blur + clip bits + trilinear gather),
     // then the camera-transform VJP over the per-corner partials
     const int* order = (const int*)point_index;
@@ -2221,8 +2250,9 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
     dg = tB;
   }
   // 3. sparse x-blur + clip mask + gather + transform VJP + reductions
-  return launch_points_bwd(st, S, P, pc, pose, trans, focal, tr_pc, dg, grid_raw, nullptr, taps_x, dtr_pc_in,
-                           nullptr, true, dpc, dpose, dtrans, dfocal, scale ? dscale : nullptr, accum, false);
+  return launch_points_bwd(st, S, P, pc, pose, trans, focal, tr_pc, dg, use_cmask ? nullptr : grid_raw,
+                           use_cmask ? clip_mask : nullptr, taps_x, dtr_pc_in, nullptr, true, dpc, dpose, dtrans,
+                           dfocal, scale ? dscale : nullptr, accum, false);
 }
 
 }  // extern "C"
