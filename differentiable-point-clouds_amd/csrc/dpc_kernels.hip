@@ -519,12 +519,16 @@ k_points_bwd(DpcShape S, DpcParams P, const float* __restrict__ pc, const float*
       gather_point<KC>(dgrid, mask, cmask ? cmask + ((size_t)b * S.N + n) * 4 : nullptr, taps_x, S.Kx, b, S.Dz, S.D,
                    tr_pc[o], tr_pc[o + 1], tr_pc[o + 2], dw, dv, du);
     if (parts) {  // one [3] slot per (corner plane k, corner row j), written by its owning WG
+      const Cell c = locate(tr_pc[o], tr_pc[o + 1], tr_pc[o + 2], S.Dz, S.D);
       const float* pp = parts + ((size_t)b * S.N + n) * 12;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        dw += pp[3 * q];
-        dv += pp[3 * q + 1];
-        du += pp[3 * q + 2];
+        // slots of corners outside the grid (and of dropped points) were never written
+        if (c.valid && c.iz + (q >> 1) < S.Dz && c.iy + (q & 1) < S.D) {
+          dw += pp[3 * q];
+          dv += pp[3 * q + 1];
+          du += pp[3 * q + 2];
+        }
       }
     }
     if (dtr_in) {
@@ -856,18 +860,30 @@ k_blur_xy_stream(const float* __restrict__ in, float* __restrict__ out, const fl
 // per touched corner (cmask [B,N,4] bytes: byte k*2+j, bit l).
 // ===========================================================================
 
-// counting sort of one view's points by depth cell iz (bin Dz = dropped points)
+// camera transform of one view's points (-> tr_pc) followed by an LDS counting
+// sort by depth cell iz (bin Dz = dropped points)
+template <bool QUAT>
 __global__ void __launch_bounds__(1024)
-k_zsort(DpcShape S, const float* __restrict__ tr_pc, int* __restrict__ order, int* __restrict__ zstart) {
+k_zsort(DpcShape S, DpcParams P, const float* __restrict__ pc, const float* __restrict__ pose,
+        const float* __restrict__ trans, const float* __restrict__ focal, float* __restrict__ tr_pc,
+        int* __restrict__ order, int* __restrict__ zstart) {
   DPC_DYN_SMEM(int, hist);  // [Dz + 2]
   const int b = blockIdx.x;
   const int N = S.N, Dz = S.Dz, D = S.D;
   const int tid = threadIdx.x, nth = blockDim.x;
   for (int i = tid; i < Dz + 2; i += nth) hist[i] = 0;
   __syncthreads();
-  const float* tp = tr_pc + (size_t)b * N * 3;
+  Pose ps;
+  load_pose<QUAT>(P, pose, trans, focal, b, ps);
+  float* tp = tr_pc + (size_t)b * N * 3;
+  const float* pp = pc + (size_t)b * N * 3;
   for (int n = tid; n < N; n += nth) {
-    const Cell c = locate(tp[3 * n], tp[3 * n + 1], tp[3 * n + 2], Dz, D);
+    float w, v, u;
+    transform_point<QUAT>(ps, pp[3 * n], pp[3 * n + 1], pp[3 * n + 2], w, v, u);
+    tp[3 * n] = w;
+    tp[3 * n + 1] = v;
+    tp[3 * n + 2] = u;
+    const Cell c = locate(w, v, u, Dz, D);
     atomicAdd(&hist[c.valid ? c.iz : Dz], 1);
   }
   __syncthreads();
@@ -883,7 +899,7 @@ k_zsort(DpcShape S, const float* __restrict__ tr_pc, int* __restrict__ order, in
   __syncthreads();
   for (int i = tid; i < Dz + 2; i += nth) zstart[(size_t)b * (Dz + 2) + i] = hist[i];
   __syncthreads();
-  for (int n = tid; n < N; n += nth) {
+  for (int n = tid; n < N; n += nth) {  // tr_pc rows written above by this same work-group
     const Cell c = locate(tp[3 * n], tp[3 * n + 1], tp[3 * n + 2], Dz, D);
     const int slot = atomicAdd(&hist[c.valid ? c.iz : Dz], 1);
     order[(size_t)b * N + slot] = n;
@@ -1863,8 +1879,6 @@ inline size_t parts_bytes(const DpcShape& S) { return align256(sizeof(float) * 1
 int launch_gather_yx(hipStream_t st, const DpcShape& S, const SplatPlan& pl, const float* dgz, const float* tr_pc,
                      const int* order, const int* zstart, const unsigned char* cmask, const float* tx,
                      const float* ty, float* parts) {
-  hipError_t e = dpc_memset("memset_parts", parts, sizeof(float) * 12 * (size_t)S.B * S.N, st);
-  if (e != hipSuccess) return (int)e;
   const int nzg = (S.Dz + DPC_GATHER_PZ - 1) / DPC_GATHER_PZ;
   const long long nblk = (long long)S.B * nzg * pl.gstrips;
   if (nblk > 0x7fffffffLL) return DPC_E_SHAPE;
@@ -1887,12 +1901,17 @@ int launch_gather_yx(hipStream_t st, const DpcShape& S, const SplatPlan& pl, con
   return last_error();
 }
 
-int launch_splat_xy(hipStream_t st, const DpcShape& S, const SplatPlan& pl, const float* tr_pc, int* order,
+int launch_splat_xy(hipStream_t st, const DpcShape& S, const DpcParams& P, const SplatPlan& pl, const float* pc,
+                    const float* pose, const float* trans, const float* focal, float* tr_pc, int* order,
                     int* zstart, const float* tx, const float* ty, float* out, unsigned char* cmask) {
   int zt = 64;
   while (zt < 1024 && zt < S.N) zt <<= 1;
-  DPC_LAUNCH("zsort", (k_zsort), dim3(S.B, 1, 1), dim3(zt, 1, 1), sizeof(int) * (size_t)(S.Dz + 2), st, S, tr_pc,
-             order, zstart);
+  if (P.pose_is_quaternion)
+    DPC_LAUNCH("zsort", (k_zsort<true>), dim3(S.B, 1, 1), dim3(zt, 1, 1), sizeof(int) * (size_t)(S.Dz + 2), st, S, P,
+               pc, pose, trans, focal, tr_pc, order, zstart);
+  else
+    DPC_LAUNCH("zsort", (k_zsort<false>), dim3(S.B, 1, 1), dim3(zt, 1, 1), sizeof(int) * (size_t)(S.Dz + 2), st, S, P,
+               pc, pose, trans, focal, tr_pc, order, zstart);
   const long long nblk = (long long)S.B * S.Dz * pl.nstrips;
   if (nblk > 0x7fffffffLL) return DPC_E_SHAPE;
   const dim3 grid((unsigned)nblk, 1, 1), block(DPC_BLOCK, 1, 1);
@@ -2115,18 +2134,11 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   const float* zin;
   int clip_in;
   if (plan.ok) {
-    // 1+2 fused front end: transform -> z-bucket -> per-plane LDS splat + clip + x,y blur
-    if (P.pose_is_quaternion)
-      DPC_LAUNCH("points_fwd", (k_points_fwd<true>), pgrid, pblock, 0, st, S, P, pc, pose, trans, focal, tr_pc,
-                 (float*)nullptr);
-    else
-      DPC_LAUNCH("points_fwd", (k_points_fwd<false>), pgrid, pblock, 0, st, S, P, pc, pose, trans, focal, tr_pc,
-                 (float*)nullptr);
-    rc = last_error();
-    if (rc) return rc;
+    // 1+2 fused front end: transform + z-bucket (one WG per view) -> per-plane LDS splat + clip + x,y blur
     int* order = (int*)point_index;                  // [B,N]   points sorted by depth cell
     int* zstart = order + (size_t)S.B * S.N;         // [B,Dz+2] bucket starts
-    rc = launch_splat_xy(st, S, plan, tr_pc, order, zstart, taps_x, taps_y, tmp, clip_mask);
+    rc = launch_splat_xy(st, S, P, plan, pc, pose, trans, focal, tr_pc, order, zstart, taps_x, taps_y, tmp,
+                         clip_mask);
     if (rc) return rc;
     zin = tmp;
     clip_in = 0;
