@@ -11,7 +11,7 @@ from ._capi import DpcError, get_library  # noqa: F401
 from .util.config import Config, default_config  # noqa: F401
 from .util.drc import drc_depth_projection, drc_event_probabilities, drc_projection  # noqa: F401
 from .util.gauss_kernel import gauss_kernel_1d, smoothing_kernel  # noqa: F401
-from .util.point_cloud import (pc_perspective_transform, pointcloud2voxels3d_fast,  # noqa: F401
+from .util.point_cloud import (pc_perspective_transform, pc_point_dropout, pointcloud2voxels3d_fast,  # noqa: F401
                                pointcloud_project_fast, smoothen_voxels3d)
 
 __version__ = "0.1.0"

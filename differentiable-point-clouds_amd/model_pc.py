@@ -15,7 +15,10 @@ import math
 import torch
 
 from .util.gauss_kernel import smoothing_kernel
-from .util.point_cloud import pointcloud_project_fast
+from .util.point_cloud import pc_point_dropout, pointcloud_project_fast
+from .util.quaternion import quaternion_conjugate as q_conj
+from .util.quaternion import quaternion_multiply as q_mul
+from .util.quaternion import quaternion_normalise as q_norm
 
 
 def tf_repeat_0(input, num):  # noqa: A002  (reference name; model_pc.py:23-32)
@@ -139,8 +142,8 @@ class ModelPointCloud(object):
             camera_pose = inputs["camera_quaternion"]
         else:
             camera_pose = inputs["matrices"]
-        if is_training and cfg.pc_point_dropout != 1:
-            raise NotImplementedError("device-side point dropout is SURVEY.md 8(f) scope")
+        if is_training and cfg.pc_point_dropout != 1:                      # model_pc.py:233-237
+            all_points, all_rgb = pc_point_dropout(all_points, all_rgb, self.get_dropout_keep_prob())
         if not cfg.pc_fast:
             raise NotImplementedError("slow exact-Gaussian path (pc_fast=false) is SURVEY.md 8(f) scope")
         predicted_translation = outputs["predicted_translation"] if cfg.predict_translation else None
@@ -176,6 +179,22 @@ class ModelPointCloud(object):
         proj_loss = (loss_tensor ** 2).sum() / 2 / float(num_samples)      # tf.nn.l2_loss
         return proj_loss, min_loss
 
+    def add_student_loss(self, inputs, outputs, min_loss, add_summary=False):    # model_pc.py:338-381
+        """Distil the winning pose candidate (teacher, no gradient) into the student
+        quaternion: sum(1 - cos^2 of half the relative angle) / num_samples * weight."""
+        cfg = self.cfg()
+        C = cfg.pose_predict_num_candidates
+        student = outputs["pose_student"]
+        teachers = outputs["poses"].reshape(-1, C, 4)
+        teachers = teachers[torch.arange(teachers.shape[0], device=teachers.device), min_loss].detach()
+        weights = inputs["valid_samples"] if cfg.variable_num_views else 1.0
+        if getattr(cfg, "pose_student_align_loss", False):
+            raise NotImplementedError("pose_student_align_loss (off by default)")
+        q_diff = q_norm(q_mul(teachers, q_conj(student)))
+        angle_diff = q_diff[:, 0]
+        student_loss = ((1.0 - angle_diff ** 2) * weights).sum() / float(min_loss.shape[0])
+        return student_loss * cfg.pose_predictor_student_loss_weight
+
     def add_proj_loss(self, inputs, outputs, weight_scale, add_summary=False):   # model_pc.py:383-423
         cfg = self.cfg()
         gt = inputs["masks"]
@@ -194,7 +213,7 @@ class ModelPointCloud(object):
             proj_loss, min_loss = self.proj_loss_pose_candidates(gt, pred, inputs)
             outputs["winning_pose_candidates"] = min_loss
             if cfg.pose_predictor_student:
-                raise NotImplementedError("pose student loss (needs the pose network, out of scope)")
+                total_loss = total_loss + self.add_student_loss(inputs, outputs, min_loss, add_summary)
         else:
             proj_loss = ((gt - pred) ** 2).sum() / 2 / float(num_samples)
         total_loss = total_loss + proj_loss

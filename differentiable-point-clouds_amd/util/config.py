@@ -33,7 +33,8 @@ class Config(dict):
         pc_num_points=8000, learn_focal_length=False,
         pc_point_dropout_scheduled=True, pc_point_dropout_exponential_schedule=False,
         pc_point_dropout_start_step=0.0, pc_point_dropout_end_step=1.0,
-        pose_predictor_student=True, variable_num_views=False,
+        pose_predictor_student=True, pose_predictor_student_loss_weight=1.0,
+        pose_student_align_loss=False, variable_num_views=False,
         # loss side (model_pc.py:383-445)
         bicubic_gt_downsampling=False, pc_gauss_filter_gt=False,
         proj_weight=1.0, drc_weight=0.0, proj_depth_weight=0.0,

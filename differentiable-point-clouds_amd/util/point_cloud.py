@@ -168,5 +168,17 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
     return ProjectionOutputs(eager, make_voxels, make_probs)
 
 
-def pc_point_dropout(points, rgb, keep_prob):
-    raise NotImplementedError("device-side point dropout is SURVEY.md 8(f) scope")
+def pc_point_dropout(points, rgb, keep_prob, generator=None):
+    """dpc/util/point_cloud.py:293-319: keep int(N * keep_prob) points per instance,
+    drawn without replacement, independently per instance (the reference calls
+    np.random.choice inside a tf.py_func, i.e. a host round trip every step; here
+    the draw is a device-side random permutation, no host sync).  The kept points
+    come out in random order, as in the reference.  Returns (points, rgb)."""
+    B, N = points.shape[0], points.shape[1]
+    num_out = int(N * float(keep_prob))
+    keys = torch.rand(B, N, device=points.device, generator=generator)
+    idx = keys.argsort(dim=1)[:, :num_out]                       # [B, num_out] distinct indices
+    gather = lambda t: torch.gather(t, 1, idx.unsqueeze(-1).expand(B, num_out, t.shape[2]))
+    out_points = gather(points)
+    out_rgb = gather(rgb) if rgb is not None else None
+    return out_points, out_rgb

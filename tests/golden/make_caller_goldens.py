@@ -57,6 +57,10 @@ def run(dtype, inp, cfg, global_step):
     all_scal = M.tf_repeat_0(model.replicate_for_multiview(tf.convert_to_tensor(scal)), C)
     outputs = {"points_1": tf.convert_to_tensor(pts), "all_points": all_points, "all_rgb": None,
                "poses": tf.convert_to_tensor(poses), "all_scaling_factors": all_scal, "all_focal_length": None}
+    student = None
+    if cfg.pose_predictor_student:
+        student = torch.tensor(inp["pose_student"], dtype=dtype, requires_grad=True)
+        outputs["pose_student"] = tf.convert_to_tensor(student)
     inputs = {"masks": tf.convert_to_tensor(masks)}
     outputs = model.compute_projection(inputs, outputs, is_training=False)
     loss = model.add_proj_loss(inputs, outputs, cfg.proj_weight, add_summary=False)
@@ -65,6 +69,8 @@ def run(dtype, inp, cfg, global_step):
                projs_depth=outputs["projs_depth"].detach().numpy(), projs_1=outputs["projs_1"].detach().numpy(),
                all_points=all_points.detach().numpy(), loss=np.asarray(float(loss)),
                dpoints=pts.grad.numpy(), dposes=poses.grad.numpy(), dscaling=scal.grad.numpy())
+    if student is not None:
+        res["dstudent"] = student.grad.numpy()
     tf.set_float_dtype(torch.float32)
     return res
 
@@ -77,11 +83,17 @@ def main():
                poses=rng.standard_normal((Bm * V * C, 4)).astype(np.float32),
                scaling_factor=rng.uniform(0.5, 1.0, (Bm, 1)).astype(np.float32),
                masks=(rng.uniform(0, 1, (Bm * V, 32, 32, 1)) > 0.6).astype(np.float32))
+    inp["pose_student"] = rng.standard_normal((Bm * V, 4)).astype(np.float32)
     gs = 150000
     out = {}
     for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
         for k, v in run(dt, inp, cfg, gs).items():
             out[k + "_" + tag] = v
+    # same case with the pose-student loss switched on (model_pc.py:338-381, weight 20)
+    cfg_s = make_cfg(pose_predictor_student=True, pose_predictor_student_loss_weight=20.0)
+    for k, v in run(torch.float64, inp, cfg_s, gs).items():
+        if k in ("loss", "dposes", "dstudent", "dpoints"):
+            out["student_" + k + "_f64"] = v
     # schedules (model_pc.py:35-64)
     steps = np.array([0, 1000, 150000, 300000, 599999], dtype=np.int64)
     sig = [float(M.get_smooth_sigma(cfg, int(s))) for s in steps]

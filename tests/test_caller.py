@@ -77,3 +77,52 @@ def test_tf_repeat_0_and_resize():
     assert torch.equal(half, img[:, ::2, ::2])                  # exact 2x: top-left sample (TF1 legacy)
     third = M.resize_images_bilinear_tf1(img, [3, 3])
     assert abs(float(third[0, 1, 1, 0]) - (2.0 + 2.0 / 3) * 9) < 1e-4   # src = 8/3 on both axes -> 9*src
+
+
+def test_pc_point_dropout_semantics():
+    """point_cloud.py:293-319: int(N*keep) distinct points per instance, drawn per instance."""
+    g = torch.Generator().manual_seed(0)
+    pts = torch.arange(2 * 50 * 3, dtype=torch.float32).reshape(2, 50, 3).requires_grad_(True)
+    out, rgb = dpc_amd.pc_point_dropout(pts, None, 0.07 * 4, generator=g)
+    assert rgb is None and out.shape == (2, 14, 3)
+    for b in range(2):
+        rows = {tuple(r.tolist()) for r in out[b].detach()}
+        assert len(rows) == 14                                         # without replacement
+        assert rows <= {tuple(r.tolist()) for r in pts[b].detach()}    # a subset of the instance's own points
+    assert not torch.equal(out[0].detach() - pts[0, 0, 0].detach(), out[1].detach() - pts[1, 0, 0].detach())
+    out.sum().backward()
+    assert int((pts.grad.abs().sum(-1) > 0).sum()) == 28              # gradient reaches exactly the kept points
+    full, _ = dpc_amd.pc_point_dropout(pts.detach(), None, 1.0)
+    assert full.shape == (2, 50, 3)
+
+
+def test_dropout_in_compute_projection(emu):
+    g = load("caller_toy")
+    cfg = _cfg(g)
+    cfg.pc_point_dropout = 0.5
+    model = M.ModelPointCloud(cfg, global_step=0, device="cpu")
+    outputs = {"points_1": torch.tensor(g["points_1"]), "poses": torch.tensor(g["poses"]),
+               "scaling_factor": torch.tensor(g["scaling_factor"]), "focal_length": None}
+    outputs = model.compute_projection({}, model.replicate_outputs(outputs), is_training=True)
+    assert outputs["projs"].shape == (8, 16, 16, 1) and torch.isfinite(outputs["projs"]).all()
+    assert outputs["proj_out"]["tr_pc"].shape[1] == int(96 * 0.5)
+
+
+def test_student_loss_matches_reference(emu):
+    """add_student_loss (model_pc.py:338-381) on top of the toy case, weight 20."""
+    g = load("caller_toy")
+    cfg = _cfg(g)
+    cfg.pose_predictor_student = True
+    cfg.pose_predictor_student_loss_weight = 20.0
+    model = M.ModelPointCloud(cfg, global_step=int(g["global_step"]), device="cpu")
+    t = lambda k, grad=True: torch.tensor(g[k], requires_grad=grad)
+    pts, poses, scal, stud = t("points_1"), t("poses"), t("scaling_factor"), t("pose_student")
+    outputs = model.replicate_outputs({"points_1": pts, "poses": poses, "scaling_factor": scal,
+                                       "focal_length": None, "pose_student": stud})
+    inputs = {"masks": t("masks", False)}
+    outputs = model.compute_projection(inputs, outputs, is_training=False)
+    loss = model.add_proj_loss(inputs, outputs, cfg.proj_weight)
+    loss.backward()
+    assert abs(float(loss) - float(g["student_loss_f64"])) < 1e-4 * float(g["student_loss_f64"])
+    assert relerr(stud.grad.numpy(), g["student_dstudent_f64"]) < 1e-4
+    assert relerr(poses.grad.numpy(), g["student_dposes_f64"]) < 2e-4
