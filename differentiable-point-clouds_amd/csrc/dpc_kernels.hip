@@ -1,32 +1,38 @@
 // dpc_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) and the
 // C ABI (include/dpc_hip.h) of the differentiable point-cloud projector.
 //
-// What runs where (per instance b; grids are [B,Dz,D,D], x fastest):
+// Fused hot path (power-of-two D in [64,256], K in {5,11,21}); grids are
+// [B,Dz,D,D], x fastest; V = bytes of one grid of one view:
 //
-//   forward   k_points_fwd     thread/point: camera transform (quaternion or
-//                              matrix) + 8 trilinear global_atomic_add_f32
-//                              into the zero-filled raw grid G0
-//             k_blur_plane     WG = (b, z, y-tile): clip + x-blur + y-blur of a
-//                              plane tile staged in LDS (odd pitches => both
-//                              passes are bank-conflict free; sliding register
-//                              windows => ~2 LDS reads / output instead of K)
-//             k_zfwd           thread = CX adjacent rays: streams the z axis
-//                              once, z-FIR in registers, writes G2 (saved) and
-//                              collapses the ray on the fly (scale, clips,
-//                              log-space DRC, depth) -> proj, depth, log T
-//   backward  k_zbwd           thread = CX rays, streams z DOWNWARD: DRC VJP
-//                              (direct suffix sums, S_j = logT - R_j in fp64),
-//                              scale/clip masks, z-FIR adjoint -> dGz, dscale
-//             k_blur_plane     y-blur only (adjoint)
-//             k_points_bwd     thread/point: x-blur evaluated ONLY at the 8
-//                              touched cells (sparse), G0 clip mask, trilinear
-//                              gather, camera-transform VJP, block reduction of
-//                              dq/dt/df, atomics into a [B,16] accumulator
-//             k_pose_finalize  quaternion normalisation Jacobian
+//   forward   k_zsort      WG/view: camera transform (quaternion or matrix) ->
+//                          tr_pc, LDS counting sort of the points by depth cell
+//             k_splat_xy   WG/(view, plane, y-strip): zero an LDS tile, ds_add_f32
+//                          the plane's points, record one clip-gradient bit per
+//                          touched corner, clip, x-blur (halo from neighbour
+//                          lanes, ds_bpermute), y-blur (rotating register FIR)
+//                          -> xy-blurred plane.                      writes 1 V
+//             k_zfwd       thread = CX adjacent rays, streams z once: register
+//                          z-FIR, writes G2 (saved), scale/clip, DRC collapse as a
+//                          running transmittance product (no log/exp), silhouette
+//                          + depth + two fp64 sums per ray.     reads 1 V, writes 1 V
+//   backward  k_zbwd       same walk: DRC VJP (suffix sum = saved total - fp64
+//                          prefix), scale/clip masks, dscale, z-FIR adjoint.
+//                                                               reads 1 V, writes 1 V
+//             k_gather_yx  WG/(view, 4 planes, y-strip): rows -> LDS (next plane
+//                          prefetched in registers), y-blur in place, sparse
+//                          x-blur + clip bits + trilinear gather at the plane's
+//                          points -> per-corner partial d(tr_pc).   reads ~1.2 V
+//             k_points_bwd thread/point: sum partials, camera-transform VJP,
+//                          block reduction of dq/dt/df into a [B,16] accumulator
+//             k_pose_finalize  quaternion normalisation Jacobian, dscale
 //
-// HBM traffic per view: forward 5 V (zero G0, r/w xy-blur, r in / w G2),
-// backward 4 V (+ sparse) against the 8 V "algorithmic" model of SURVEY.md 8(d).
-// No MFMA: this is scatter / stencil / scan work bounded by HBM.
+// Generic path (any D, odd K <= 63, max-collapse, no blur, stage-level API):
+//   k_points_fwd (transform + 8 global_atomic_add_f32 into zero-filled G0),
+//   k_blur_xy_stream / k_blur_plane (plane blur, LDS-free / LDS-tiled),
+//   k_blur_z / k_blur_z_generic, k_scatter, k_gather, k_max_fwd/bwd.
+//
+// No MFMA: this is scatter / stencil / scan work bounded by HBM (and, before
+// the rewrites recorded in profiles/, by VALU issue and LDS crossbar time).
 //
 // The same source compiles for the CPU-only test tier with -DDPC_EMU (see
 // tests/hipemu/hip_emu.h); that build is never loaded by the product.
@@ -46,19 +52,10 @@
 
 #include <math.h>
 
-// Lanes of one wave execute in lock-step on the GPU; the thread-per-lane CPU
-// emulation needs an explicit rendezvous where a wave reads and then overwrites
-// the same LDS row.
+// DPC_PINGPONG=1 alternates two register buffers in the z kernels instead of
+// copying the prefetched group (A/B on MI355X: neutral; kept as a tuning switch)
 #ifndef DPC_PINGPONG
 #define DPC_PINGPONG 0
-#endif
-#ifndef DPC_SPLAT_SHFL
-#define DPC_SPLAT_SHFL 0
-#endif
-#ifdef DPC_EMU
-#define DPC_WAVE_SYNC() __syncthreads()
-#else
-#define DPC_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 
 #include <mutex>
@@ -136,7 +133,13 @@ namespace {
 // ---------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------
+// clip_by_value = max(min(v, hi), lo); one v_med3_f32 on the GPU (inputs are never NaN here:
+// NaN points are dropped before the grid)
+#ifdef DPC_EMU
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fmaxf(fminf(v, hi), lo); }
+#else
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+#endif
 
 struct Quat {
   float w, x, y, z;
