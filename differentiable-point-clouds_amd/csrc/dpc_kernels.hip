@@ -141,6 +141,13 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fm
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 #endif
 
+// 1/x, 1 ulp (v_rcp_f32); x is in [eps, 1] here
+#ifdef DPC_EMU
+__device__ __forceinline__ float dpc_rcp(float x) { return 1.0f / x; }
+#else
+__device__ __forceinline__ float dpc_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+
 struct Quat {
   float w, x, y, z;
 };
@@ -735,30 +742,49 @@ __device__ __forceinline__ void store_cx(float* __restrict__ p, const float (&v)
 // unrolled over a group of G steps (G a multiple of K) the slot of logical
 // accumulator k at step u is (k + u) % K, a compile-time constant, so no
 // register-to-register shifting is ever executed.
+typedef float dpc_v2f __attribute__((vector_size(8)));  // one v_pk_fma_f32 operand pair
+
 template <int KC, int CX>
 struct ZFir {
-  float acc[KC][CX];
+  static constexpr int NP = CX / 2;        // packed pairs (explicit 2-vectors => v_pk_fma_f32)
+  static constexpr int NS = CX - 2 * NP;   // odd leftover lane value
+  dpc_v2f accp[KC][NP > 0 ? NP : 1];
+  float accs[KC][NS > 0 ? NS : 1];
   float tp[KC];
   __device__ __forceinline__ void init(const float* __restrict__ taps) {
 #pragma unroll
     for (int j = 0; j < KC; ++j) {
       tp[j] = taps ? taps[j] : 1.0f;
 #pragma unroll
-      for (int c = 0; c < CX; ++c) acc[j][c] = 0.f;
+      for (int c = 0; c < NP; ++c) accp[j][c] = dpc_v2f{0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NS; ++c) accs[j][c] = 0.f;
     }
   }
   // u = step index inside the unrolled group (compile-time after unrolling)
   __device__ __forceinline__ void push(const float (&v)[CX], float (&out)[CX], int u) {
+    dpc_v2f vp[NP > 0 ? NP : 1];
+#pragma unroll
+    for (int c = 0; c < NP; ++c) vp[c] = dpc_v2f{v[2 * c], v[2 * c + 1]};
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
       const float t = tp[KC - 1 - k];
+      const dpc_v2f tt = dpc_v2f{t, t};
 #pragma unroll
-      for (int c = 0; c < CX; ++c) acc[(k + u) % KC][c] += t * v[c];
+      for (int c = 0; c < NP; ++c) accp[(k + u) % KC][c] += tt * vp[c];
+#pragma unroll
+      for (int c = 0; c < NS; ++c) accs[(k + u) % KC][c] += t * v[2 * NP + c];
     }
 #pragma unroll
-    for (int c = 0; c < CX; ++c) {
-      out[c] = acc[u % KC][c];
-      acc[u % KC][c] = 0.f;
+    for (int c = 0; c < NP; ++c) {
+      out[2 * c] = accp[u % KC][c][0];
+      out[2 * c + 1] = accp[u % KC][c][1];
+      accp[u % KC][c] = dpc_v2f{0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+      out[2 * NP + c] = accs[u % KC][c];
+      accs[u % KC][c] = 0.f;
     }
   }
 };
@@ -1292,7 +1318,7 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
   const float e_eps = expf(eps);
   const bool has_s = scale != nullptr;
   const float s = has_s ? scale[b] : 1.0f;
-  const float fDz = (float)Dz;
+  const float rDz = 1.0f / (float)Dz;  // psi_i = i/Dz - 0.5 + cd (drc.py:139-143); exact for power-of-two Dz
   ZFir<KC, CX> fir;
   fir.init(taps);
   float Tr[CX];
@@ -1319,7 +1345,7 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
         if (t >= h) {
           const int o = t - h;
           if (g2_out) store_cx<CX>(g2_out + base + (size_t)o * ncol, g2);
-          const float psi = (float)o / fDz - 0.5f + P.camera_distance;
+          const float psi = (float)o * rDz - 0.5f + P.camera_distance;
           float pv[CX];
 #pragma unroll
           for (int c = 0; c < CX; ++c) {
@@ -1409,7 +1435,7 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
     const float e_eps = expf(eps);
     const bool has_s = scale != nullptr;
     const float s = has_s ? scale[b] : 1.0f;
-    const float fDz = (float)Dz;
+    const float rDz = 1.0f / (float)Dz;  // psi_i = i/Dz - 0.5 + cd (drc.py:139-143); exact for power-of-two Dz
     float g[CX], gd[CX], Tr[CX];
     double tot[CX];
 #pragma unroll
@@ -1433,7 +1459,7 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
       for (int j = 0; j < Dz; ++j) {
         float v[CX];
         load_cx<CX>(g2_in + base + (size_t)j * ncol, v);
-        const float psi = (float)j / fDz - 0.5f + P.camera_distance;
+        const float psi = (float)j * rDz - 0.5f + P.camera_distance;
 #pragma unroll
         for (int c = 0; c < CX; ++c) {
           const float g3 = has_s ? clampf(v[c] * s, 0.f, 1.f) : v[c];
@@ -1463,7 +1489,7 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
         if (j < T) {
           float dg2[CX], o[CX];
           if (j < Dz) {
-            const float psi = (float)j / fDz - 0.5f + P.camera_distance;
+            const float psi = (float)j * rDz - 0.5f + P.camera_distance;
 #pragma unroll
             for (int c = 0; c < CX; ++c) {
               const float vv = buf[u][c];
@@ -1476,7 +1502,7 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
               if (dprobs) gam += dprobs[((size_t)j * B + b) * ncol + ocol + c];
               const float gT = gam * Tq;           // = a_j / c_j
               tot[c] -= (double)(gT * cc);          // a_j = gamma_j p_j
-              const float dc = gT - __fdividef((float)tot[c], omc);
+              const float dc = gT - (float)tot[c] * dpc_rcp(omc);
               const float dg3 = (cc == g3) ? dc : 0.f;   // eps <= G3 <= 1-eps  <=>  the clip was inactive
               Tr[c] *= omc;
               if (has_s) {

@@ -78,3 +78,47 @@ def odd_sizes_and_generic_tap_counts(dev, D, K):
     assert relerr(g[0].cpu().numpy(), bw["dpc"]) < TOL_GRAD
     assert relerr(g[1].cpu().numpy(), bw["dpose"]) < TOL_GRAD
     assert relerr(g[2].cpu().numpy(), bw["dscale"]) < TOL_GRAD
+
+
+FUSED_CASES = [
+    # (B, N, D, Dz, K, sigma, with_trans, with_focal)  -- shapes that take the fused LDS splat / gather path
+    (3, 300, 64, 64, 11, 1.3, True, False),      # B not a multiple of 8, N not a multiple of 64
+    (2, 500, 64, 32, 11, 1.5, False, True),      # vox_size_z != vox_size: Kz = 5 (gauss_kernel.py:38-50)
+    (2, 400, 64, 64, 21, 3.0, False, False),     # the shipped experiments' kernel size
+    (2, 40, 64, 64, 5, 0.8, False, False),       # fewer points than one wave
+]
+
+
+def fused_path_against_numpy_oracle(dev, B, N, D, Dz, K, sigma, with_trans, with_focal):
+    """pointcloud_project_fast on shapes that use k_zsort/k_splat_xy/k_gather_yx,
+    forward and all gradients (incl. depth upstream) vs the float64 NumPy oracle."""
+    rng = np.random.default_rng(1000 + B * 7 + N)
+    inp = synth.make_inputs(B, N, 900 + N)
+    trans = (0.04 * rng.standard_normal((B, 3))).astype(np.float32) if with_trans else None
+    focal = rng.uniform(1.7, 2.1, (B, 1)).astype(np.float32) if with_focal else None
+    cfg = dpc_amd.default_config(vox_size=D, vox_size_z=(Dz if Dz != D else -1), pc_gauss_kernel_size=K)
+    lib = dpc_amd.get_library()
+    S = dpc_amd._capi.DpcShape(B, N, Dz, D, K, K, 1)
+    P = dpc_amd._capi.DpcParams(2.0, 1.875, 1e-5, 10.0, 1, 0, 0)
+    import ctypes
+    assert lib.dpc_saved_layout(ctypes.byref(S), ctypes.byref(P)) == 6, "expected the fused path for this shape"
+    t = lambda a: None if a is None else torch.tensor(a, device=dev, requires_grad=True)
+    pc, pose, scale, ttrans, tfocal = t(inp["pc"]), t(inp["pose"]), t(inp["scale"]), t(trans), t(focal)
+    kern = dpc_amd.smoothing_kernel(cfg, sigma, device=dev)
+    out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, ttrans, None, kern, scaling_factor=scale, focal_length=tfocal)
+    w = rng.standard_normal(out["proj"].shape)
+    wd = 0.1 * rng.standard_normal(out["proj"].shape)
+    loss = (out["proj"] * torch.tensor(w, dtype=torch.float32, device=dev)).sum() + \
+           (out["proj_depth"] * torch.tensor(wd, dtype=torch.float32, device=dev)).sum()
+    leaves = [x for x in (pc, pose, scale, ttrans, tfocal) if x is not None]
+    grads = torch.autograd.grad(loss, leaves)
+    f64 = lambda a: None if a is None else a.astype(np.float64)
+    taps = onp.smoothing_taps(D, Dz if Dz != D else -1, K, sigma)
+    fw = onp.project_forward(f64(inp["pc"]), f64(inp["pose"]), f64(trans), f64(inp["scale"]), f64(focal), taps, Dz=Dz, D=D)
+    bw = onp.project_backward(f64(inp["pc"]), f64(inp["pose"]), f64(trans), f64(inp["scale"]), f64(focal), taps, fw,
+                              dproj=w, dproj_depth=wd)
+    assert maxabs(out["proj"].detach().cpu().numpy(), fw["proj"]) < TOL_PROJ
+    assert maxabs(out["proj_depth"].detach().cpu().numpy(), fw["proj_depth"]) < TOL_DEPTH
+    names = ["dpc", "dpose", "dscale"] + (["dtrans"] if with_trans else []) + (["dfocal"] if with_focal else [])
+    for name, g in zip(names, grads):
+        assert relerr(g.cpu().numpy().reshape(bw[name].shape), bw[name]) < TOL_GRAD, name

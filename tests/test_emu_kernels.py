@@ -63,3 +63,8 @@ def test_emu_nan_points_dropped(emu):
     res, _ = run_product("tiny_nan", g, "cpu", grads=False)
     assert np.isfinite(res["proj"]).all()
     assert maxabs(res["proj"], g["proj_f64"]) < TOL_PROJ
+
+
+@pytest.mark.parametrize("case", parity_cases.FUSED_CASES[:2])
+def test_emu_fused_path_against_numpy_oracle(emu, case):
+    parity_cases.fused_path_against_numpy_oracle("cpu", *case)

@@ -136,6 +136,11 @@ def test_odd_sizes_and_generic_tap_counts(D, K):
     parity_cases.odd_sizes_and_generic_tap_counts("cuda", D, K)
 
 
+@pytest.mark.parametrize("case", parity_cases.FUSED_CASES)
+def test_fused_path_against_numpy_oracle(case):
+    parity_cases.fused_path_against_numpy_oracle("cuda", *case)
+
+
 def test_cfg5_stress_shape_runs():
     """BASELINE configs[4]: 16000 pts -> 256^3, sigma 2.0 (reduced to B=2 here;
     bench.py --config 5 runs B=8)."""
