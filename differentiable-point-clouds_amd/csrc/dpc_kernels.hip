@@ -954,15 +954,34 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
   const int RT = SH + 2 * h;
   const int tid = threadIdx.x, nth = blockDim.x;
 
+  const int* zs = zstart + (size_t)b * (Dz + 2);
+  const int lo = zs[z > 0 ? z - 1 : 0], mid = zs[z], hi = zs[z + 1];
+  const float* tp = tr_pc + (size_t)b * N * 3;
+
+  // 0. sparsity: point clouds are surfaces, most (plane, strip) tiles see no point at all.
+  //    Such a tile blurs to exactly zero: store zeros and leave.
+  {
+    int touched = 0;
+    for (int i = lo + tid; i < hi; i += nth) {
+      const int n = order[(size_t)b * N + i];
+      const Cell c = locate(tp[3 * n], tp[3 * n + 1], tp[3 * n + 2], Dz, D);
+      touched |= (c.iy + 1 >= y0 - h) && (c.iy < y0 + SH + h);
+    }
+    if (!__syncthreads_or(touched)) {
+      float* oplane = out + (size_t)pz * D * D + (size_t)y0 * D;
+      const int n4 = (SH < D - y0 ? SH : D - y0) * D;
+      for (int i = tid * 4; i < n4; i += nth * 4)
+        *reinterpret_cast<float4*>(oplane + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
+  }
+
   // 1. zero the tile
   for (int i = tid * 4; i < RT * D; i += nth * 4)
     *reinterpret_cast<float4*>(tile + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
 
   // 2. splat the points of depth cells z-1 (upper corner, k=1) and z (k=0)
-  const int* zs = zstart + (size_t)b * (Dz + 2);
-  const int lo = zs[z > 0 ? z - 1 : 0], mid = zs[z], hi = zs[z + 1];
-  const float* tp = tr_pc + (size_t)b * N * 3;
   for (int i = lo + tid; i < hi; i += nth) {
     const int n = order[(size_t)b * N + i];
     const int k = (i < mid) ? 1 : 0;
@@ -1131,10 +1150,27 @@ k_gather_yx(DpcShape S, const float* __restrict__ dgz, const float* __restrict__
     }
   };
   const int zbeg = zg * DPC_GATHER_PZ;
-  prefetch(zbeg);
+  // sparsity: a (plane, strip) pair none of whose rows is a corner row of some point
+  // contributes nothing -- it is neither loaded nor blurred
+  unsigned need = 0;
   for (int zi = 0; zi < DPC_GATHER_PZ; ++zi) {
     const int z = zbeg + zi;
-    if (z >= Dz) break;  // uniform
+    int owns = 0;
+    if (z < Dz) {
+      const int lo = zs[z > 0 ? z - 1 : 0], hi = zs[z + 1];
+      for (int i = lo + tid; i < hi; i += nth) {
+        const int n = order[(size_t)b * N + i];
+        const Cell c = locate(tp[3 * n], tp[3 * n + 1], tp[3 * n + 2], Dz, D);
+        owns |= (c.iy + 1 >= y0) && (c.iy < y0 + SH);
+      }
+    }
+    if (__syncthreads_or(owns)) need |= 1u << zi;
+  }
+  bool have_pre = false;
+  for (int zi = 0; zi < DPC_GATHER_PZ; ++zi) {
+    const int z = zbeg + zi;
+    if (!((need >> zi) & 1u)) continue;  // uniform
+    if (!have_pre) prefetch(z);
     // 1. registers -> LDS (rows outside the grid are zero)
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
@@ -1149,7 +1185,8 @@ k_gather_yx(DpcShape S, const float* __restrict__ dgz, const float* __restrict__
       }
     }
     __syncthreads();
-    if (zi + 1 < DPC_GATHER_PZ) prefetch(z + 1);  // in flight during steps 2-3
+    have_pre = (zi + 1 < DPC_GATHER_PZ) && ((need >> (zi + 1)) & 1u);
+    if (have_pre) prefetch(z + 1);  // in flight during steps 2-3
 
     // 2. y-blur (adjoint of the forward y-blur: same symmetric taps), outputs in registers
     float outr[RS][VY];

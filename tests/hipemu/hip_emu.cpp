@@ -6,6 +6,7 @@ thread_local Ctx t_ctx;
 pthread_barrier_t* g_barrier = nullptr;
 unsigned char* g_dyn_smem = nullptr;
 unsigned int* g_xchg = nullptr;
+int g_vote = 0;
 
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
   const unsigned nthreads = block.x * block.y * block.z;

@@ -64,6 +64,18 @@ inline void sync() { pthread_barrier_wait(g_barrier); }
 
 static inline void __syncthreads() { hipemu::sync(); }
 
+namespace hipemu { extern int g_vote; }
+static inline int __syncthreads_or(int pred) {
+  hipemu::sync();
+  if (hipemu::t_ctx.flat == 0) __atomic_store_n(&hipemu::g_vote, 0, __ATOMIC_RELAXED);
+  hipemu::sync();
+  if (pred) __atomic_store_n(&hipemu::g_vote, 1, __ATOMIC_RELAXED);
+  hipemu::sync();
+  const int r = __atomic_load_n(&hipemu::g_vote, __ATOMIC_RELAXED);
+  hipemu::sync();
+  return r;
+}
+
 static inline float atomicAdd(float* p, float v) {
   uint32_t* ip = reinterpret_cast<uint32_t*>(p);
   uint32_t old = __atomic_load_n(ip, __ATOMIC_RELAXED);
