@@ -976,9 +976,11 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
     }
   }
 
-  // 1. zero the tile
+  // 1. zero the tile and the per-row "some point landed here" flags
+  int* rowflag = reinterpret_cast<int*>(tile + RT * D);  // [RT]
   for (int i = tid * 4; i < RT * D; i += nth * 4)
     *reinterpret_cast<float4*>(tile + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < RT; i += nth) rowflag[i] = 0;
   __syncthreads();
 
   // 2. splat the points of depth cells z-1 (upper corner, k=1) and z (k=0)
@@ -994,6 +996,7 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
       const int yy = c.iy + j;
       const int t = yy - (y0 - h);
       if (yy >= D || t < 0 || t >= RT) continue;
+      rowflag[t] = 1;  // benign race: every writer stores 1
 #pragma unroll
       for (int l = 0; l < 2; ++l) {
         const int xx = c.ix + l;
@@ -1040,6 +1043,7 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
   for (int t0 = 0; t0 < RT; t0 += nstream) {
     const int t = t0 + stream;
     const bool rowok = t < RT;
+    if (!__any(rowok && rowflag[rowok ? t : 0])) continue;  // wave-uniform: untouched rows stay zero
     float v[4], xb[4];
     load_cx<4>(tile + (rowok ? t : 0) * D + lx * 4, v);
 #pragma unroll
@@ -1076,10 +1080,22 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
   const int ly = lane & (LRy - 1);
   const int nsy = nth / LRy;
   const int RS = SH / nsy;
-  ZFir<KC, VY> fir;
-  fir.init(taps_y);
   const int steps = RS + 2 * h;
   float* oplane = out + (size_t)pz * D * D;
+  int live = 0;
+  for (int q = 0; q < steps; ++q) live |= rowflag[sy * RS + q];
+  if (!live) {  // every input row of this stream is zero => so are its RS output rows
+    float zero[VY];
+#pragma unroll
+    for (int c = 0; c < VY; ++c) zero[c] = 0.f;
+    for (int r = 0; r < RS; ++r) {
+      const int gy = y0 + sy * RS + r;
+      if (gy < D) store_cx<VY>(oplane + (size_t)gy * D + ly * VY, zero);
+    }
+    return;
+  }
+  ZFir<KC, VY> fir;
+  fir.init(taps_y);
   for (int q0 = 0; q0 < steps; q0 += G) {
 #pragma unroll
     for (int u = 0; u < G; ++u) {
@@ -1928,7 +1944,7 @@ SplatPlan splat_plan(const DpcShape& S) {
   p.SH = SH;
   p.nstrips = D / SH;
   p.lr_shift = lr_shift;
-  p.lds_bytes = sizeof(float) * (size_t)(SH + 2 * (K / 2)) * D;
+  p.lds_bytes = sizeof(float) * (size_t)(SH + 2 * (K / 2)) * (D + 1);  // tile + per-row flags
   return p;
 }
 inline size_t point_index_ints(const DpcShape& S) { return (size_t)S.B * S.N + (size_t)S.B * (S.Dz + 2); }

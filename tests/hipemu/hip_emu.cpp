@@ -6,6 +6,7 @@ thread_local Ctx t_ctx;
 pthread_barrier_t* g_barrier = nullptr;
 unsigned char* g_dyn_smem = nullptr;
 unsigned int* g_xchg = nullptr;
+pthread_barrier_t* g_wave_barriers = nullptr;
 int g_vote = 0;
 
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
@@ -17,6 +18,13 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
   g_dyn_smem = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(dyn.data()) + 63) & ~uintptr_t(63));
   std::vector<unsigned int> xchg(nthreads);
   g_xchg = xchg.data();
+  const unsigned nwaves = (nthreads + 63) / 64;
+  std::vector<pthread_barrier_t> wbar(nwaves);
+  for (unsigned w = 0; w < nwaves; ++w) {
+    const unsigned cnt = (w + 1) * 64 <= nthreads ? 64 : nthreads - w * 64;
+    pthread_barrier_init(&wbar[w], nullptr, cnt);
+  }
+  g_wave_barriers = wbar.data();
   auto worker = [&](unsigned flat) {
     Ctx& c = t_ctx;
     c.flat = flat;
@@ -36,6 +44,8 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
   for (unsigned i = 0; i < nthreads; ++i) th.emplace_back(worker, i);
   for (auto& t : th) t.join();
   pthread_barrier_destroy(&barrier);
+  for (auto& wb : wbar) pthread_barrier_destroy(&wb);
+  g_wave_barriers = nullptr;
   g_barrier = nullptr;
   g_dyn_smem = nullptr;
   g_xchg = nullptr;

@@ -53,8 +53,10 @@ extern thread_local Ctx t_ctx;
 extern pthread_barrier_t* g_barrier;
 extern unsigned char* g_dyn_smem;
 extern unsigned int* g_xchg;   // per-thread 32-bit exchange words for shuffles
+extern pthread_barrier_t* g_wave_barriers;  // one per wave64 of the block
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
 inline void sync() { pthread_barrier_wait(g_barrier); }
+inline void wave_sync() { pthread_barrier_wait(&g_wave_barriers[t_ctx.flat >> 6]); }
 }  // namespace hipemu
 
 #define threadIdx (hipemu::t_ctx.tid)
@@ -95,41 +97,54 @@ static inline float atomicAdd(float* p, float v) {
 
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
-// wave64 shuffles through the exchange buffer (block-uniform control flow only)
+// wave64 shuffles / votes through the exchange buffer; they rendezvous per WAVE, so
+// they may sit in wave-uniform (not necessarily block-uniform) control flow, as on the GPU
 static inline float __shfl_down(float v, unsigned delta, int width = 64) {
   (void)width;
   unsigned f = hipemu::t_ctx.flat;
   memcpy(&hipemu::g_xchg[f], &v, 4);
-  hipemu::sync();
+  hipemu::wave_sync();
   unsigned lane = f & 63u;
   unsigned nthreads = hipemu::t_ctx.bdim.x * hipemu::t_ctx.bdim.y * hipemu::t_ctx.bdim.z;
   float r = v;
   if (lane + delta < 64u && f + delta < nthreads) memcpy(&r, &hipemu::g_xchg[f + delta], 4);
-  hipemu::sync();
+  hipemu::wave_sync();
+  return r;
+}
+// wave-level vote (block-uniform control flow only, like the shuffles)
+static inline int __any(int pred) {
+  unsigned f = hipemu::t_ctx.flat;
+  hipemu::g_xchg[f] = pred ? 1u : 0u;
+  hipemu::wave_sync();
+  unsigned nthreads = hipemu::t_ctx.bdim.x * hipemu::t_ctx.bdim.y * hipemu::t_ctx.bdim.z;
+  unsigned base = f & ~63u;
+  int r = 0;
+  for (unsigned i = base; i < base + 64u && i < nthreads; ++i) r |= (int)hipemu::g_xchg[i];
+  hipemu::wave_sync();
   return r;
 }
 static inline float __shfl(float v, int src_lane, int width = 64) {
   (void)width;
   unsigned f = hipemu::t_ctx.flat;
   memcpy(&hipemu::g_xchg[f], &v, 4);
-  hipemu::sync();
+  hipemu::wave_sync();
   unsigned nthreads = hipemu::t_ctx.bdim.x * hipemu::t_ctx.bdim.y * hipemu::t_ctx.bdim.z;
   unsigned src = (f & ~63u) | ((unsigned)src_lane & 63u);
   float r = v;
   if (src < nthreads) memcpy(&r, &hipemu::g_xchg[src], 4);
-  hipemu::sync();
+  hipemu::wave_sync();
   return r;
 }
 static inline float __shfl_xor(float v, int mask, int width = 64) {
   (void)width;
   unsigned f = hipemu::t_ctx.flat;
   memcpy(&hipemu::g_xchg[f], &v, 4);
-  hipemu::sync();
+  hipemu::wave_sync();
   unsigned nthreads = hipemu::t_ctx.bdim.x * hipemu::t_ctx.bdim.y * hipemu::t_ctx.bdim.z;
   unsigned src = (f & ~63u) | ((f & 63u) ^ (unsigned)mask);
   float r = v;
   if (src < nthreads) memcpy(&r, &hipemu::g_xchg[src], 4);
-  hipemu::sync();
+  hipemu::wave_sync();
   return r;
 }
 
