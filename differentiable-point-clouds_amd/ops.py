@@ -6,6 +6,7 @@ csrc/dpc_kernels.hip.  Tensors must be float32 on a ROCm device.
 """
 import collections
 import ctypes
+import os
 
 import torch
 
@@ -104,12 +105,20 @@ def _taps_of(taps):
     return tuple(ts), tuple(ks)
 
 
+def _poison(t):
+    """DPC_POISON_BUFFERS=1 (set by the test-suite): NaN-fill every buffer the kernels are supposed
+    to fully define or deliberately skip, so that a read of a never-written element cannot hide."""
+    if t is not None and os.environ.get("DPC_POISON_BUFFERS") and t.is_floating_point():
+        t.fill_(float("nan"))
+    return t
+
+
 class _Workspace(object):
     """256-byte aligned scratch carved out of a torch allocation."""
 
     def __init__(self, lib, shape, direction, like):
         self.nbytes = lib.dpc_workspace_bytes(ctypes.byref(shape), direction)
-        self.buf = torch.empty((self.nbytes + 256 + 3) // 4, dtype=torch.float32, device=like.device)
+        self.buf = _poison(torch.empty((self.nbytes + 256 + 3) // 4, dtype=torch.float32, device=like.device))
         base = self.buf.data_ptr()
         self.ptr = ctypes.c_void_p((base + 255) & ~255)
 
@@ -130,13 +139,16 @@ class ProjectFused(torch.autograd.Function):
         B, N = pc.shape[0], pc.shape[1]
         Dz, D = meta.Dz, meta.D
         shape, params = _shape(B, N, meta, K), _params(meta)
-        new = lambda *s, **kw: torch.empty(*s, dtype=kw.get("dtype", torch.float32), device=pc.device)
+        new = lambda *s, **kw: _poison(torch.empty(*s, dtype=kw.get("dtype", torch.float32), device=pc.device))
         tr_pc = new(B, N, 3)
         layout = lib.dpc_saved_layout(ctypes.byref(shape), ctypes.byref(params))
         lib.check(min(layout, 0), "dpc_saved_layout")
         grid_raw = new(B, Dz, D, D) if layout & 1 else None
         clip_mask = new(B, N, 4, dtype=torch.uint8) if layout & 2 else None
-        point_index = new(B * N + B * (Dz + 2), dtype=torch.int32) if layout & 4 else None
+        point_index = None
+        if layout & 4:
+            n_idx = lib.dpc_point_index_ints(ctypes.byref(shape), ctypes.byref(params))
+            point_index = new(n_idx, dtype=torch.int32)
         grid_blur = new(B, Dz, D, D)
         drc = meta.collapse_mode == _capi.DPC_COLLAPSE_DRC
         logt = new(B, D, D, 2, dtype=torch.float64) if drc else None
@@ -171,7 +183,7 @@ class ProjectFused(torch.autograd.Function):
             ddepth = None
             if dproj is None:
                 dproj = torch.zeros(B, meta.D, meta.D, 1, dtype=torch.float32, device=pc.device)
-        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=pc.device)
+        new = lambda *s: _poison(torch.empty(*s, dtype=torch.float32, device=pc.device))
         dpc = new(B, N, 3)
         dpose = torch.empty_like(pose)
         dtrans = new(B, 3) if trans is not None else None

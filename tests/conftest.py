@@ -9,6 +9,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+os.environ.setdefault("DPC_POISON_BUFFERS", "1")   # NaN-fill kernel buffers: unwritten reads cannot hide
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -98,7 +98,8 @@ def fused_path_against_numpy_oracle(dev, B, N, D, Dz, K, sigma, with_trans, with
     focal = rng.uniform(1.7, 2.1, (B, 1)).astype(np.float32) if with_focal else None
     cfg = dpc_amd.default_config(vox_size=D, vox_size_z=(Dz if Dz != D else -1), pc_gauss_kernel_size=K)
     lib = dpc_amd.get_library()
-    S = dpc_amd._capi.DpcShape(B, N, Dz, D, K, K, 1)
+    Kz = len(onp.smoothing_taps(D, Dz if Dz != D else -1, K, sigma)[2])
+    S = dpc_amd._capi.DpcShape(B, N, Dz, D, K, K, Kz)
     P = dpc_amd._capi.DpcParams(2.0, 1.875, 1e-5, 10.0, 1, 0, 0)
     import ctypes
     assert lib.dpc_saved_layout(ctypes.byref(S), ctypes.byref(P)) == 6, "expected the fused path for this shape"
