@@ -941,7 +941,8 @@ __global__ void __launch_bounds__(DPC_BLOCK)
 k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ order,
            const int* __restrict__ zstart, const float* __restrict__ taps_x,
            const float* __restrict__ taps_y, float* __restrict__ out, unsigned char* __restrict__ cmask,
-           unsigned char* __restrict__ rowflags /*[B,Dz,D/RS] out*/, int SH, int nstrips, int lr_shift) {
+           unsigned char* __restrict__ rowflags /*[B,Dz,D/RS] out*/, int SH, int nstrips, int lr_shift,
+           int dense_out /*1: also store the all-zero row groups (consumers ignore the flags)*/) {
   DPC_DYN_SMEM(float, tile);
   constexpr int h = KC / 2;
   constexpr int G = zgroup(KC);
@@ -971,6 +972,12 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
       // nothing is stored: the consumers (k_zfwd, k_zbwd) see the cleared flags
       const int nsy0 = nth / (D / VY);        // y-streams per strip = row groups per strip
       if (tid < nsy0) rowflags[(size_t)pz * (nstrips * nsy0) + strip * nsy0 + tid] = 0;
+      if (dense_out) {
+        float* oplane = out + (size_t)pz * D * D + (size_t)y0 * D;
+        const int n4 = (SH < D - y0 ? SH : D - y0) * D;
+        for (int i = tid * 4; i < n4; i += nth * 4)
+          *reinterpret_cast<float4*>(oplane + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       return;
     }
   }
@@ -1084,7 +1091,18 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
   int live = 0;
   for (int q = 0; q < steps; ++q) live |= rowflag[sy * RS + q];
   if (ly == 0) rowflags[(size_t)pz * (nstrips * nsy) + strip * nsy + sy] = live ? 1 : 0;
-  if (!live) return;  // every input row of this stream is zero => so are its RS output rows (not stored)
+  if (!live) {  // every input row of this stream is zero => so are its RS output rows
+    if (dense_out) {
+      float zero[VY];
+#pragma unroll
+      for (int c = 0; c < VY; ++c) zero[c] = 0.f;
+      for (int r = 0; r < RS; ++r) {
+        const int gy = y0 + sy * RS + r;
+        if (gy < D) store_cx<VY>(oplane + (size_t)gy * D + ly * VY, zero);
+      }
+    }
+    return;
+  }
   ZFir<KC, VY> fir;
   fir.init(taps_y);
   for (int q0 = 0; q0 < steps; q0 += G) {
@@ -1263,21 +1281,66 @@ __device__ __forceinline__ void zload(const float* __restrict__ base, int ncol, 
 // Row-group liveness flags written by k_splat_xy: fl[(b*Dz + z)*NG + row/GRP] == 0 means that
 // group of rows of the xy-blurred plane z is exactly zero and was NOT stored.  Since the z-blur
 // only mixes planes, rows of G2 are zero (and not stored either) wherever the flags of planes
-// z-h..z+h are all 0.  fl == nullptr: dense (everything live).
-__device__ __forceinline__ bool live_window(const unsigned char* __restrict__ fl, int NG, int j, int h, int Dz) {
-  if (!fl) return true;
-  const int lo = j - h < 0 ? 0 : j - h, hi = j + h >= Dz ? Dz - 1 : j + h;
-  int any = 0;
-  for (int i = lo; i <= hi; ++i) any |= fl[(size_t)i * NG];
-  return any != 0;
+// z-h..z+h are all 0.  A wave's rays all lie in one row group (the host guarantees it), so the
+// wave gathers the flags of all planes once (one byte per lane, __ballot) into a <= 256-bit mask
+// held in scalar registers; every later test is a couple of scalar shifts.
+struct LiveMask {
+  unsigned long long m0, m1, m2, m3;
+  bool dense;
+  __device__ __forceinline__ int bit(int t, int Dz) const {
+    if (dense) return (t >= 0 && t < Dz) ? 1 : 0;
+    if (t < 0 || t >= Dz) return 0;
+    const int w = t >> 6;
+    const unsigned long long m = w == 0 ? m0 : (w == 1 ? m1 : (w == 2 ? m2 : m3));
+    return (int)((m >> (t & 63)) & 1ull);
+  }
+  // any live plane in [lo, hi] (clipped to the grid)?  lo, hi are wave-uniform => scalar code
+  __device__ __forceinline__ bool any(int lo, int hi, int Dz) const {
+    lo = lo < 0 ? 0 : lo;
+    hi = hi >= Dz ? Dz - 1 : hi;
+    if (lo > hi) return false;
+    if (dense) return true;
+    const unsigned long long mm[4] = {m0, m1, m2, m3};
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int a = lo - 64 * w, b = hi - 64 * w;     // range in this word's coordinates
+      if (b < 0 || a > 63) continue;
+      const int aa = a < 0 ? 0 : a, bb = b > 63 ? 63 : b;
+      const unsigned long long mask = ((~0ull) >> (63 - bb)) & ((~0ull) << aa);
+      acc |= mm[w] & mask;
+    }
+    return acc != 0;
+  }
+};
+// must be called by all 64 lanes of the wave; fl already points at (view b, this wave's row group)
+__device__ __forceinline__ LiveMask load_live(const unsigned char* __restrict__ fl, int NG, int Dz) {
+  LiveMask L;
+  L.dense = (fl == nullptr);
+  L.m0 = L.m1 = L.m2 = L.m3 = ~0ull;
+  if (!L.dense) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long mm[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int z = w * 64 + lane;
+      const int zc = z < Dz ? z : Dz - 1;
+      const int live = (z < Dz) && (fl[(size_t)zc * NG] != 0);
+      mm[w] = __ballot(live);
+    }
+    L.m0 = mm[0];
+    L.m1 = mm[1];
+    L.m2 = mm[2];
+    L.m3 = mm[3];
+  }
+  return L;
 }
-// plane t of the kernel's input when only live row groups exist in memory (w = window half-width
-// of the liveness test: 0 for the xy-blurred planes, h for G2)
+// plane t of the kernel's input when only live row groups exist in memory
 template <int CX>
-__device__ __forceinline__ void zload_live(const float* __restrict__ base, int ncol, int t, int Dz,
-                                           const unsigned char* __restrict__ fl, int NG, int w, float (&v)[CX]) {
+__device__ __forceinline__ void zload_live(const float* __restrict__ base, int ncol, int t, int Dz, bool live,
+                                           float (&v)[CX]) {
   const int tc = t < 0 ? 0 : (t < Dz ? t : Dz - 1);
-  if (live_window(fl, NG, tc, w, Dz)) {
+  if (live) {
     load_cx<CX>(base + (size_t)tc * ncol, v);
   } else {
 #pragma unroll
@@ -1369,13 +1432,14 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
   const int b = blockIdx.y;
   const int ncol = D * D;
   const int col = (blockIdx.x * blockDim.x + threadIdx.x) * CX;
+  const int yq = (col < ncol ? col : ncol - 1) / D;
+  const LiveMask LM = load_live(rowflags ? rowflags + (size_t)b * Dz * NG + yq / GRP : nullptr, NG, Dz);
   if (col >= ncol) return;
   const size_t base = (size_t)b * Dz * ncol + col;
   const int y = col / D, x0 = col - y * D;
   const int ocol = (flip_h ? (D - 1 - y) : y) * D + x0;
   constexpr int h = KC / 2;
   constexpr int G = zgroup(KC);
-  const unsigned char* fl = rowflags ? rowflags + (size_t)b * Dz * NG + y / GRP : nullptr;
   const float eps = P.eps, one_m = 1.0f - P.eps;
   const float e_eps = expf(eps);
   const bool has_s = scale != nullptr;
@@ -1406,7 +1470,8 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
         fir.push(v, g2, u);
         if (t >= h) {
           const int o = t - h;
-          if (g2_out && live_window(fl, NG, o, h, Dz)) store_cx<CX>(g2_out + base + (size_t)o * ncol, g2);
+          // G2 plane o is zero (and not stored) unless one of its input planes o-h..o+h is live
+          if (g2_out && LM.any(o - h, o + h, Dz)) store_cx<CX>(g2_out + base + (size_t)o * ncol, g2);
           const float psi = (float)o * rDz - 0.5f + P.camera_distance;
           float pv[CX];
 #pragma unroll
@@ -1427,20 +1492,20 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
   // two groups of planes in flight, roles alternate (no register copies)
   float bufA[G][CX], bufB[G][CX];
 #pragma unroll
-  for (int u = 0; u < G; ++u) zload_live<CX>(in + base, ncol, u, Dz, fl, NG, 0, bufA[u]);
+  for (int u = 0; u < G; ++u) zload_live<CX>(in + base, ncol, u, Dz, LM.bit(u, Dz) != 0, bufA[u]);
 #if DPC_PINGPONG
   for (int t0 = 0; t0 < T; t0 += 2 * G) {
 #pragma unroll
-    for (int u = 0; u < G; ++u) zload_live<CX>(in + base, ncol, t0 + G + u, Dz, fl, NG, 0, bufB[u]);
+    for (int u = 0; u < G; ++u) zload_live<CX>(in + base, ncol, t0 + G + u, Dz, LM.bit(t0 + G + u, Dz) != 0, bufB[u]);
     process(bufA, t0);
 #pragma unroll
-    for (int u = 0; u < G; ++u) zload_live<CX>(in + base, ncol, t0 + 2 * G + u, Dz, fl, NG, 0, bufA[u]);
+    for (int u = 0; u < G; ++u) zload_live<CX>(in + base, ncol, t0 + 2 * G + u, Dz, LM.bit(t0 + 2 * G + u, Dz) != 0, bufA[u]);
     process(bufB, t0 + G);
   }
 #else
   for (int t0 = 0; t0 < T; t0 += G) {
 #pragma unroll
-    for (int u = 0; u < G; ++u) zload_live<CX>(in + base, ncol, t0 + G + u, Dz, fl, NG, 0, bufB[u]);
+    for (int u = 0; u < G; ++u) zload_live<CX>(in + base, ncol, t0 + G + u, Dz, LM.bit(t0 + G + u, Dz) != 0, bufB[u]);
     process(bufA, t0);
 #pragma unroll
     for (int u = 0; u < G; ++u)
@@ -1486,6 +1551,8 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
   const int ncol = D * D;
   const int col = (blockIdx.x * blockDim.x + threadIdx.x) * CX;
   const bool active = col < ncol;
+  const int yq = (active ? col : ncol - 1) / D;
+  const LiveMask LM = load_live(rowflags ? rowflags + (size_t)b * Dz * NG + yq / GRP : nullptr, NG, Dz);
   float dsacc[1] = {0.f};
   if (active) {
     const size_t base = (size_t)b * Dz * ncol + col;
@@ -1493,7 +1560,8 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
     const int ocol = (flip_h ? (D - 1 - y) : y) * D + x0;
     constexpr int h = KC / 2;
     constexpr int G = zgroup(KC);
-    const unsigned char* fl = rowflags ? rowflags + (size_t)b * Dz * NG + y / GRP : nullptr;
+    // G2 plane j exists in memory iff one of the xy planes j-h..j+h is live
+    auto g2live = [&](int j) { return LM.any(j - h, j + h, Dz); };
     const float eps = P.eps, one_m = 1.0f - P.eps;
     const float e_eps = expf(eps);
     const bool has_s = scale != nullptr;
@@ -1521,7 +1589,7 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
       }
       for (int j = 0; j < Dz; ++j) {
         float v[CX];
-        zload_live<CX>(g2_in + base, ncol, j, Dz, fl, NG, h, v);
+        zload_live<CX>(g2_in + base, ncol, j, Dz, g2live(j), v);
         const float psi = (float)j * rDz - 0.5f + P.camera_distance;
 #pragma unroll
         for (int c = 0; c < CX; ++c) {
@@ -1587,20 +1655,20 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
     };
     float bufA[G][CX], bufB[G][CX];
 #pragma unroll
-    for (int u = 0; u < G; ++u) zload_live<CX>(g2_in + base, ncol, u, Dz, fl, NG, h, bufA[u]);
+    for (int u = 0; u < G; ++u) zload_live<CX>(g2_in + base, ncol, u, Dz, g2live(u), bufA[u]);
 #if DPC_PINGPONG
     for (int t0 = 0; t0 < T; t0 += 2 * G) {
 #pragma unroll
-      for (int u = 0; u < G; ++u) zload_live<CX>(g2_in + base, ncol, t0 + G + u, Dz, fl, NG, h, bufB[u]);
+      for (int u = 0; u < G; ++u) zload_live<CX>(g2_in + base, ncol, t0 + G + u, Dz, g2live(t0 + G + u), bufB[u]);
       process(bufA, t0);
 #pragma unroll
-      for (int u = 0; u < G; ++u) zload_live<CX>(g2_in + base, ncol, t0 + 2 * G + u, Dz, fl, NG, h, bufA[u]);
+      for (int u = 0; u < G; ++u) zload_live<CX>(g2_in + base, ncol, t0 + 2 * G + u, Dz, g2live(t0 + 2 * G + u), bufA[u]);
       process(bufB, t0 + G);
     }
 #else
     for (int t0 = 0; t0 < T; t0 += G) {
 #pragma unroll
-      for (int u = 0; u < G; ++u) zload_live<CX>(g2_in + base, ncol, t0 + G + u, Dz, fl, NG, h, bufB[u]);
+      for (int u = 0; u < G; ++u) zload_live<CX>(g2_in + base, ncol, t0 + G + u, Dz, g2live(t0 + G + u), bufB[u]);
       process(bufA, t0);
 #pragma unroll
       for (int u = 0; u < G; ++u)
@@ -1929,12 +1997,13 @@ struct SplatPlan {
   int gSH, gRS, gstrips;  // k_gather_yx strips (gSH == 0: not applicable)
   size_t glds_bytes;
   int GRP, NG;            // row-group liveness flags: GRP rows per group, NG groups per plane
+  bool sparse;            // zero row groups are not stored / not read (else flags are all 1)
 };
 inline bool z_fixed(int K);
 // The fused path needs the fused consumers (k_zfwd / k_zbwd honour the liveness flags), i.e. the
 // DRC collapse and a compile-time z tap count.
 SplatPlan splat_plan(const DpcShape& S, const DpcParams& P) {
-  SplatPlan p = {false, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  SplatPlan p = {false, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, false};
   const int D = S.D, K = S.Kx;
   if (S.Kx != S.Ky || (K != 5 && K != 11 && K != 21)) return p;
   if (P.collapse_mode != DPC_COLLAPSE_DRC || !z_fixed(S.Kz)) return p;
@@ -1950,6 +2019,13 @@ SplatPlan splat_plan(const DpcShape& S, const DpcParams& P) {
   if (nsy < 1 || SH % nsy != 0) return p;
   p.GRP = SH / nsy;
   p.NG = D / p.GRP;
+  {
+    // liveness flags are consumed per WAVE by the z kernels: all rays of a wave (64 * CX
+    // columns) must fall into one row group, and the per-wave plane mask holds 256 planes
+    const int cx = pick_cx(D);
+    const int rows_per_wave = (64 * cx + D - 1) / D;
+    p.sparse = (S.Dz <= 256) && (p.GRP % rows_per_wave == 0) && ((64 * cx) % D == 0 || D % (64 * cx) == 0);
+  }
   // k_gather_yx: one LDS tile of gSH + 2h rows, gRS = gSH / nsy rows per y-stream in {16, 8},
   // at most 10 16-byte loads per thread and plane; otherwise backward uses the generic kernels
   p.gSH = 0;
@@ -2025,7 +2101,8 @@ int launch_splat_xy(hipStream_t st, const DpcShape& S, const DpcParams& P, const
   const dim3 grid((unsigned)nblk, 1, 1), block(DPC_BLOCK, 1, 1);
 #define DPC_SP(KC, VY)                                                                                     \
   DPC_LAUNCH("splat_xy", (k_splat_xy<KC, VY>), grid, block, pl.lds_bytes, st, S, tr_pc, (const int*)order, \
-             (const int*)zstart, tx, ty, out, cmask, rowflags, pl.SH, pl.nstrips, pl.lr_shift)
+             (const int*)zstart, tx, ty, out, cmask, rowflags, pl.SH, pl.nstrips, pl.lr_shift,    \
+             pl.sparse ? 0 : 1)
 #define DPC_SPV(KC)                \
   do {                             \
     if (pl.vy == 2) DPC_SP(KC, 2); \
@@ -2278,7 +2355,7 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   }
   // 3. z blur fused with the ray collapse (fused path: only live row groups exist in memory)
   if (drc && z_fixed(S.Kz)) {
-    const unsigned char* fl = plan.ok ? rowflags_of(point_index, S) : nullptr;
+    const unsigned char* fl = (plan.ok && plan.sparse) ? rowflags_of(point_index, S) : nullptr;
     return launch_zfwd(st, S, P, zin, taps_z, S.Kz, scale, grid_blur, nullptr, proj, proj_depth, ray_sums,
                        clip_in, 1, fl, plan.NG, plan.GRP);
   }
@@ -2341,7 +2418,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   float* ds_acc = scale ? accum : nullptr;
   // 1. collapse VJP (+ z-FIR adjoint) -> tA
   if (drc && z_fixed(S.Kz)) {
-    const unsigned char* fl = use_cmask ? rowflags_of(point_index, S) : nullptr;
+    const unsigned char* fl = (use_cmask && plan.sparse) ? rowflags_of(point_index, S) : nullptr;
     rc = launch_zbwd(st, S, P, grid_blur, taps_z, S.Kz, scale, ray_sums, dproj, dproj_depth, nullptr, tA,
                      ds_acc, 1, fl, plan.NG, plan.GRP);
     if (rc) return rc;

@@ -111,6 +111,18 @@ static inline float __shfl_down(float v, unsigned delta, int width = 64) {
   hipemu::wave_sync();
   return r;
 }
+static inline unsigned long long __ballot(int pred) {
+  unsigned f = hipemu::t_ctx.flat;
+  hipemu::g_xchg[f] = pred ? 1u : 0u;
+  hipemu::wave_sync();
+  unsigned nthreads = hipemu::t_ctx.bdim.x * hipemu::t_ctx.bdim.y * hipemu::t_ctx.bdim.z;
+  unsigned base = f & ~63u;
+  unsigned long long r = 0;
+  for (unsigned i = 0; i < 64u && base + i < nthreads; ++i)
+    if (hipemu::g_xchg[base + i]) r |= 1ull << i;
+  hipemu::wave_sync();
+  return r;
+}
 // wave-level vote (block-uniform control flow only, like the shuffles)
 static inline int __any(int pred) {
   unsigned f = hipemu::t_ctx.flat;
