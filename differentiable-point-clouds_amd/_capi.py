@@ -53,7 +53,6 @@ SIGNATURES = {
                                        ctypes.POINTER(ctypes.c_float)]),
     "dpc_debug_copy": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, ctypes.c_int]),
     "dpc_saved_layout": (ctypes.c_int, [_SP, _PP]),
-    "dpc_point_index_ints": (ctypes.c_size_t, [_SP, _PP]),
     "dpc_project_forward": (ctypes.c_int, [_P, _SP, _PP] + [_P] * 8 + [_P] * 8 + [_P, ctypes.c_size_t]),
     "dpc_project_backward": (ctypes.c_int, [_P, _SP, _PP] + [_P] * 8 + [_P] * 6 + [_P] * 3 + [_P] * 5
                              + [_P, ctypes.c_size_t]),

@@ -941,8 +941,7 @@ __global__ void __launch_bounds__(DPC_BLOCK)
 k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ order,
            const int* __restrict__ zstart, const float* __restrict__ taps_x,
            const float* __restrict__ taps_y, float* __restrict__ out, unsigned char* __restrict__ cmask,
-           unsigned char* __restrict__ rowflags /*[B,Dz,D/RS] out*/, int SH, int nstrips, int lr_shift,
-           int dense_out /*1: also store the all-zero row groups (consumers ignore the flags)*/) {
+           int SH, int nstrips, int lr_shift) {
   DPC_DYN_SMEM(float, tile);
   constexpr int h = KC / 2;
   constexpr int G = zgroup(KC);
@@ -969,15 +968,10 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
       touched |= (c.iy + 1 >= y0 - h) && (c.iy < y0 + SH + h);
     }
     if (!__syncthreads_or(touched)) {
-      // nothing is stored: the consumers (k_zfwd, k_zbwd) see the cleared flags
-      const int nsy0 = nth / (D / VY);        // y-streams per strip = row groups per strip
-      if (tid < nsy0) rowflags[(size_t)pz * (nstrips * nsy0) + strip * nsy0 + tid] = 0;
-      if (dense_out) {
-        float* oplane = out + (size_t)pz * D * D + (size_t)y0 * D;
-        const int n4 = (SH < D - y0 ? SH : D - y0) * D;
-        for (int i = tid * 4; i < n4; i += nth * 4)
-          *reinterpret_cast<float4*>(oplane + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      float* oplane = out + (size_t)pz * D * D + (size_t)y0 * D;
+      const int n4 = (SH < D - y0 ? SH : D - y0) * D;
+      for (int i = tid * 4; i < n4; i += nth * 4)
+        *reinterpret_cast<float4*>(oplane + i) = make_float4(0.f, 0.f, 0.f, 0.f);
       return;
     }
   }
@@ -1090,16 +1084,13 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
   float* oplane = out + (size_t)pz * D * D;
   int live = 0;
   for (int q = 0; q < steps; ++q) live |= rowflag[sy * RS + q];
-  if (ly == 0) rowflags[(size_t)pz * (nstrips * nsy) + strip * nsy + sy] = live ? 1 : 0;
   if (!live) {  // every input row of this stream is zero => so are its RS output rows
-    if (dense_out) {
-      float zero[VY];
+    float zero[VY];
 #pragma unroll
-      for (int c = 0; c < VY; ++c) zero[c] = 0.f;
-      for (int r = 0; r < RS; ++r) {
-        const int gy = y0 + sy * RS + r;
-        if (gy < D) store_cx<VY>(oplane + (size_t)gy * D + ly * VY, zero);
-      }
+    for (int c = 0; c < VY; ++c) zero[c] = 0.f;
+    for (int r = 0; r < RS; ++r) {
+      const int gy = y0 + sy * RS + r;
+      if (gy < D) store_cx<VY>(oplane + (size_t)gy * D + ly * VY, zero);
     }
     return;
   }
@@ -1278,76 +1269,6 @@ __device__ __forceinline__ void zload(const float* __restrict__ base, int ncol, 
   load_cx<CX>(base + (size_t)tc * ncol, v);
 }
 
-// Row-group liveness flags written by k_splat_xy: fl[(b*Dz + z)*NG + row/GRP] == 0 means that
-// group of rows of the xy-blurred plane z is exactly zero and was NOT stored.  Since the z-blur
-// only mixes planes, rows of G2 are zero (and not stored either) wherever the flags of planes
-// z-h..z+h are all 0.  A wave's rays all lie in one row group (the host guarantees it), so the
-// wave gathers the flags of all planes once (one byte per lane, __ballot) into a <= 256-bit mask
-// held in scalar registers; every later test is a couple of scalar shifts.
-struct LiveMask {
-  unsigned long long m0, m1, m2, m3;
-  bool dense;
-  __device__ __forceinline__ int bit(int t, int Dz) const {
-    if (dense) return (t >= 0 && t < Dz) ? 1 : 0;
-    if (t < 0 || t >= Dz) return 0;
-    const int w = t >> 6;
-    const unsigned long long m = w == 0 ? m0 : (w == 1 ? m1 : (w == 2 ? m2 : m3));
-    return (int)((m >> (t & 63)) & 1ull);
-  }
-  // any live plane in [lo, hi] (clipped to the grid)?  lo, hi are wave-uniform => scalar code
-  __device__ __forceinline__ bool any(int lo, int hi, int Dz) const {
-    lo = lo < 0 ? 0 : lo;
-    hi = hi >= Dz ? Dz - 1 : hi;
-    if (lo > hi) return false;
-    if (dense) return true;
-    const unsigned long long mm[4] = {m0, m1, m2, m3};
-    unsigned long long acc = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const int a = lo - 64 * w, b = hi - 64 * w;     // range in this word's coordinates
-      if (b < 0 || a > 63) continue;
-      const int aa = a < 0 ? 0 : a, bb = b > 63 ? 63 : b;
-      const unsigned long long mask = ((~0ull) >> (63 - bb)) & ((~0ull) << aa);
-      acc |= mm[w] & mask;
-    }
-    return acc != 0;
-  }
-};
-// must be called by all 64 lanes of the wave; fl already points at (view b, this wave's row group)
-__device__ __forceinline__ LiveMask load_live(const unsigned char* __restrict__ fl, int NG, int Dz) {
-  LiveMask L;
-  L.dense = (fl == nullptr);
-  L.m0 = L.m1 = L.m2 = L.m3 = ~0ull;
-  if (!L.dense) {
-    const int lane = threadIdx.x & 63;
-    unsigned long long mm[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const int z = w * 64 + lane;
-      const int zc = z < Dz ? z : Dz - 1;
-      const int live = (z < Dz) && (fl[(size_t)zc * NG] != 0);
-      mm[w] = __ballot(live);
-    }
-    L.m0 = mm[0];
-    L.m1 = mm[1];
-    L.m2 = mm[2];
-    L.m3 = mm[3];
-  }
-  return L;
-}
-// plane t of the kernel's input when only live row groups exist in memory
-template <int CX>
-__device__ __forceinline__ void zload_live(const float* __restrict__ base, int ncol, int t, int Dz, bool live,
-                                           float (&v)[CX]) {
-  const int tc = t < 0 ? 0 : (t < Dz ? t : Dz - 1);
-  if (live) {
-    load_cx<CX>(base + (size_t)tc * ncol, v);
-  } else {
-#pragma unroll
-    for (int c = 0; c < CX; ++c) v[c] = 0.f;
-  }
-}
-
 // plain z blur, compile-time K
 template <int KC, int CX>
 __global__ void __launch_bounds__(DPC_BLOCK)
@@ -1428,12 +1349,10 @@ __global__ void __launch_bounds__(DPC_BLOCK)
 k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps,
        const float* __restrict__ scale, float* __restrict__ g2_out, float* __restrict__ probs,
        float* __restrict__ proj, float* __restrict__ depth, double* __restrict__ sums, int B, int Dz,
-       int D, int clip_in, int flip_h, const unsigned char* __restrict__ rowflags, int NG, int GRP) {
+       int D, int clip_in, int flip_h) {
   const int b = blockIdx.y;
   const int ncol = D * D;
   const int col = (blockIdx.x * blockDim.x + threadIdx.x) * CX;
-  const int yq = (col < ncol ? col : ncol - 1) / D;
-  const LiveMask LM = load_live(rowflags ? rowflags + (size_t)b * Dz * NG + yq / GRP : nullptr, NG, Dz);
   if (col >= ncol) return;
   const size_t base = (size_t)b * Dz * ncol + col;
   const int y = col / D, x0 = col - y * D;
@@ -1470,8 +1389,7 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
         fir.push(v, g2, u);
         if (t >= h) {
           const int o = t - h;
-          // G2 plane o is zero (and not stored) unless one of its input planes o-h..o+h is live
-          if (g2_out && LM.any(o - h, o + h, Dz)) store_cx<CX>(g2_out + base + (size_t)o * ncol, g2);
+          if (g2_out) store_cx<CX>(g2_out + base + (size_t)o * ncol, g2);
           const float psi = (float)o * rDz - 0.5f + P.camera_distance;
           float pv[CX];
 #pragma unroll
@@ -1492,20 +1410,20 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
   // two groups of planes in flight, roles alternate (no register copies)
   float bufA[G][CX], bufB[G][CX];
 #pragma unroll
-  for (int u = 0; u < G; ++u) zload_live<CX>(in + base, ncol, u, Dz, LM.bit(u, Dz) != 0, bufA[u]);
+  for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, u, Dz, bufA[u]);
 #if DPC_PINGPONG
   for (int t0 = 0; t0 < T; t0 += 2 * G) {
 #pragma unroll
-    for (int u = 0; u < G; ++u) zload_live<CX>(in + base, ncol, t0 + G + u, Dz, LM.bit(t0 + G + u, Dz) != 0, bufB[u]);
+    for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, t0 + G + u, Dz, bufB[u]);
     process(bufA, t0);
 #pragma unroll
-    for (int u = 0; u < G; ++u) zload_live<CX>(in + base, ncol, t0 + 2 * G + u, Dz, LM.bit(t0 + 2 * G + u, Dz) != 0, bufA[u]);
+    for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, t0 + 2 * G + u, Dz, bufA[u]);
     process(bufB, t0 + G);
   }
 #else
   for (int t0 = 0; t0 < T; t0 += G) {
 #pragma unroll
-    for (int u = 0; u < G; ++u) zload_live<CX>(in + base, ncol, t0 + G + u, Dz, LM.bit(t0 + G + u, Dz) != 0, bufB[u]);
+    for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, t0 + G + u, Dz, bufB[u]);
     process(bufA, t0);
 #pragma unroll
     for (int u = 0; u < G; ++u)
@@ -1546,13 +1464,11 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
        const float* __restrict__ scale, const double* __restrict__ sums,
        const float* __restrict__ dproj, const float* __restrict__ ddepth,
        const float* __restrict__ dprobs, float* __restrict__ dgz, float* __restrict__ dscale, int B,
-       int Dz, int D, int flip_h, const unsigned char* __restrict__ rowflags, int NG, int GRP) {
+       int Dz, int D, int flip_h) {
   const int b = blockIdx.y;
   const int ncol = D * D;
   const int col = (blockIdx.x * blockDim.x + threadIdx.x) * CX;
   const bool active = col < ncol;
-  const int yq = (active ? col : ncol - 1) / D;
-  const LiveMask LM = load_live(rowflags ? rowflags + (size_t)b * Dz * NG + yq / GRP : nullptr, NG, Dz);
   float dsacc[1] = {0.f};
   if (active) {
     const size_t base = (size_t)b * Dz * ncol + col;
@@ -1560,8 +1476,6 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
     const int ocol = (flip_h ? (D - 1 - y) : y) * D + x0;
     constexpr int h = KC / 2;
     constexpr int G = zgroup(KC);
-    // G2 plane j exists in memory iff one of the xy planes j-h..j+h is live
-    auto g2live = [&](int j) { return LM.any(j - h, j + h, Dz); };
     const float eps = P.eps, one_m = 1.0f - P.eps;
     const float e_eps = expf(eps);
     const bool has_s = scale != nullptr;
@@ -1589,7 +1503,7 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
       }
       for (int j = 0; j < Dz; ++j) {
         float v[CX];
-        zload_live<CX>(g2_in + base, ncol, j, Dz, g2live(j), v);
+        load_cx<CX>(g2_in + base + (size_t)j * ncol, v);
         const float psi = (float)j * rDz - 0.5f + P.camera_distance;
 #pragma unroll
         for (int c = 0; c < CX; ++c) {
@@ -1655,20 +1569,20 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
     };
     float bufA[G][CX], bufB[G][CX];
 #pragma unroll
-    for (int u = 0; u < G; ++u) zload_live<CX>(g2_in + base, ncol, u, Dz, g2live(u), bufA[u]);
+    for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, u, Dz, bufA[u]);
 #if DPC_PINGPONG
     for (int t0 = 0; t0 < T; t0 += 2 * G) {
 #pragma unroll
-      for (int u = 0; u < G; ++u) zload_live<CX>(g2_in + base, ncol, t0 + G + u, Dz, g2live(t0 + G + u), bufB[u]);
+      for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, t0 + G + u, Dz, bufB[u]);
       process(bufA, t0);
 #pragma unroll
-      for (int u = 0; u < G; ++u) zload_live<CX>(g2_in + base, ncol, t0 + 2 * G + u, Dz, g2live(t0 + 2 * G + u), bufA[u]);
+      for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, t0 + 2 * G + u, Dz, bufA[u]);
       process(bufB, t0 + G);
     }
 #else
     for (int t0 = 0; t0 < T; t0 += G) {
 #pragma unroll
-      for (int u = 0; u < G; ++u) zload_live<CX>(g2_in + base, ncol, t0 + G + u, Dz, g2live(t0 + G + u), bufB[u]);
+      for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, t0 + G + u, Dz, bufB[u]);
       process(bufA, t0);
 #pragma unroll
       for (int u = 0; u < G; ++u)
@@ -1923,14 +1837,13 @@ int launch_blur_z(hipStream_t st, const DpcShape& S, const float* in, float* out
 // in -> (z-FIR Kz) -> collapse.  Kz must be z_fixed().
 int launch_zfwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const float* in, const float* tz,
                 int Kz, const float* scale, float* g2_out, float* probs, float* proj, float* depth,
-                double* sums, int clip_in, int flip_h, const unsigned char* rowflags = nullptr, int NG = 1,
-                int GRP = 1) {
+                double* sums, int clip_in, int flip_h) {
   const dim3 block(DPC_BLOCK, 1, 1);
   const int cx = pick_cx(S.D);
   const dim3 grid = col_grid(S, cx);
 #define DPC_M(KC, CXV)                                                                                \
   DPC_LAUNCH("zfwd", (k_zfwd<KC, CXV>), grid, block, 0, st, P, in, (Kz > 0 ? tz : (const float*)nullptr), scale, \
-             g2_out, probs, proj, depth, sums, S.B, S.Dz, S.D, clip_in, flip_h, rowflags, NG, GRP)
+             g2_out, probs, proj, depth, sums, S.B, S.Dz, S.D, clip_in, flip_h)
   DPC_Z_DISPATCH(Kz, cx, DPC_M);
 #undef DPC_M
   return last_error();
@@ -1938,14 +1851,13 @@ int launch_zfwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const flo
 
 int launch_zbwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const float* g2, const float* tz,
                 int Kz, const float* scale, const double* sums, const float* dproj, const float* ddepth,
-                const float* dprobs, float* dgz, float* dscale, int flip_h,
-                const unsigned char* rowflags = nullptr, int NG = 1, int GRP = 1) {
+                const float* dprobs, float* dgz, float* dscale, int flip_h) {
   const dim3 block(DPC_BLOCK, 1, 1);
   const int cx = pick_cx(S.D);
   const dim3 grid = col_grid(S, cx);
 #define DPC_M(KC, CXV)                                                                                \
   DPC_LAUNCH("zbwd", (k_zbwd<KC, CXV>), grid, block, 0, st, P, g2, (Kz > 0 ? tz : (const float*)nullptr), scale, \
-             sums, dproj, ddepth, dprobs, dgz, dscale, S.B, S.Dz, S.D, flip_h, rowflags, NG, GRP)
+             sums, dproj, ddepth, dprobs, dgz, dscale, S.B, S.Dz, S.D, flip_h)
   DPC_Z_DISPATCH(Kz, cx, DPC_M);
 #undef DPC_M
   return last_error();
@@ -1996,17 +1908,11 @@ struct SplatPlan {
   size_t lds_bytes;
   int gSH, gRS, gstrips;  // k_gather_yx strips (gSH == 0: not applicable)
   size_t glds_bytes;
-  int GRP, NG;            // row-group liveness flags: GRP rows per group, NG groups per plane
-  bool sparse;            // zero row groups are not stored / not read (else flags are all 1)
 };
-inline bool z_fixed(int K);
-// The fused path needs the fused consumers (k_zfwd / k_zbwd honour the liveness flags), i.e. the
-// DRC collapse and a compile-time z tap count.
-SplatPlan splat_plan(const DpcShape& S, const DpcParams& P) {
-  SplatPlan p = {false, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, false};
+SplatPlan splat_plan(const DpcShape& S) {
+  SplatPlan p = {false, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int D = S.D, K = S.Kx;
   if (S.Kx != S.Ky || (K != 5 && K != 11 && K != 21)) return p;
-  if (P.collapse_mode != DPC_COLLAPSE_DRC || !z_fixed(S.Kz)) return p;
   if (D < 32 || D > 256 || (D & (D - 1)) != 0 || S.N <= 0) return p;
   int lr_shift = 0;
   while ((4 << lr_shift) < D) ++lr_shift;
@@ -2017,15 +1923,6 @@ SplatPlan splat_plan(const DpcShape& S, const DpcParams& P) {
   p.vy = (D <= 128) ? 2 : 4;              // y-phase floats per lane (k_splat_xy step 5)
   const int nsy = DPC_BLOCK / (D / p.vy);
   if (nsy < 1 || SH % nsy != 0) return p;
-  p.GRP = SH / nsy;
-  p.NG = D / p.GRP;
-  {
-    // liveness flags are consumed per WAVE by the z kernels: all rays of a wave (64 * CX
-    // columns) must fall into one row group, and the per-wave plane mask holds 256 planes
-    const int cx = pick_cx(D);
-    const int rows_per_wave = (64 * cx + D - 1) / D;
-    p.sparse = (S.Dz <= 256) && (p.GRP % rows_per_wave == 0) && ((64 * cx) % D == 0 || D % (64 * cx) == 0);
-  }
   // k_gather_yx: one LDS tile of gSH + 2h rows, gRS = gSH / nsy rows per y-stream in {16, 8},
   // at most 10 16-byte loads per thread and plane; otherwise backward uses the generic kernels
   p.gSH = 0;
@@ -2050,13 +1947,7 @@ SplatPlan splat_plan(const DpcShape& S, const DpcParams& P) {
   p.lds_bytes = sizeof(float) * (size_t)(SH + 2 * (K / 2)) * (D + 1);  // tile + per-row flags
   return p;
 }
-// saved index buffer: [B,N] sorted point ids | [B,Dz+2] bucket starts | [B,Dz,NG] liveness bytes
-inline size_t point_index_ints(const DpcShape& S, const SplatPlan& pl) {
-  return (size_t)S.B * S.N + (size_t)S.B * (S.Dz + 2) + ((size_t)S.B * S.Dz * pl.NG + 3) / 4;
-}
-inline unsigned char* rowflags_of(const int32_t* point_index, const DpcShape& S) {
-  return (unsigned char*)(point_index + (size_t)S.B * S.N + (size_t)S.B * (S.Dz + 2));
-}
+inline size_t point_index_ints(const DpcShape& S) { return (size_t)S.B * S.N + (size_t)S.B * (S.Dz + 2); }
 inline size_t parts_bytes(const DpcShape& S) { return align256(sizeof(float) * 12 * (size_t)S.B * S.N); }
 
 int launch_gather_yx(hipStream_t st, const DpcShape& S, const SplatPlan& pl, const float* dgz, const float* tr_pc,
@@ -2086,8 +1977,7 @@ int launch_gather_yx(hipStream_t st, const DpcShape& S, const SplatPlan& pl, con
 
 int launch_splat_xy(hipStream_t st, const DpcShape& S, const DpcParams& P, const SplatPlan& pl, const float* pc,
                     const float* pose, const float* trans, const float* focal, float* tr_pc, int* order,
-                    int* zstart, const float* tx, const float* ty, float* out, unsigned char* cmask,
-                    unsigned char* rowflags) {
+                    int* zstart, const float* tx, const float* ty, float* out, unsigned char* cmask) {
   int zt = 64;
   while (zt < 1024 && zt < S.N) zt <<= 1;
   if (P.pose_is_quaternion)
@@ -2101,8 +1991,7 @@ int launch_splat_xy(hipStream_t st, const DpcShape& S, const DpcParams& P, const
   const dim3 grid((unsigned)nblk, 1, 1), block(DPC_BLOCK, 1, 1);
 #define DPC_SP(KC, VY)                                                                                     \
   DPC_LAUNCH("splat_xy", (k_splat_xy<KC, VY>), grid, block, pl.lds_bytes, st, S, tr_pc, (const int*)order, \
-             (const int*)zstart, tx, ty, out, cmask, rowflags, pl.SH, pl.nstrips, pl.lr_shift,    \
-             pl.sparse ? 0 : 1)
+             (const int*)zstart, tx, ty, out, cmask, pl.SH, pl.nstrips, pl.lr_shift)
 #define DPC_SPV(KC)                \
   do {                             \
     if (pl.vy == 2) DPC_SP(KC, 2); \
@@ -2131,13 +2020,7 @@ int dpc_profile_enable(int on) {
 
 int dpc_saved_layout(const DpcShape* shape, const DpcParams* params) {
   if (check_shape(shape, true) != DPC_OK || !params) return DPC_E_SHAPE;
-  return splat_plan(*shape, *params).ok ? 6 : 1;  // bit 0: grid_raw; bits 1+2: clip_mask + point_index
-}
-
-size_t dpc_point_index_ints(const DpcShape* shape, const DpcParams* params) {
-  if (check_shape(shape, true) != DPC_OK || !params) return 0;
-  const SplatPlan pl = splat_plan(*shape, *params);
-  return pl.ok ? point_index_ints(*shape, pl) : 0;
+  return splat_plan(*shape).ok ? 6 : 1;  // bit 0: grid_raw; bits 1+2: clip_mask + point_index
 }
 
 int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, int width) {
@@ -2312,7 +2195,7 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   const bool drc = P.collapse_mode == DPC_COLLAPSE_DRC;
   if (!drc && P.collapse_mode != DPC_COLLAPSE_MAX) return DPC_E_MODE;
   if (drc && !ray_sums) return DPC_E_NULL;
-  const SplatPlan plan = splat_plan(S, P);
+  const SplatPlan plan = splat_plan(S);
   if (plan.ok ? (!clip_mask || !point_index) : !grid_raw) return DPC_E_NULL;
   const bool plane = S.Kx > 0 || S.Ky > 0;
   if (plane && (!workspace || workspace_bytes < dpc_workspace_bytes(shape, 0) ||
@@ -2329,7 +2212,7 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
     int* order = (int*)point_index;                  // [B,N]   points sorted by depth cell
     int* zstart = order + (size_t)S.B * S.N;         // [B,Dz+2] bucket starts
     rc = launch_splat_xy(st, S, P, plan, pc, pose, trans, focal, tr_pc, order, zstart, taps_x, taps_y, tmp,
-                         clip_mask, rowflags_of(point_index, S));
+                         clip_mask);
     if (rc) return rc;
     zin = tmp;
     clip_in = 0;
@@ -2353,13 +2236,10 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
       clip_in = 0;
     }
   }
-  // 3. z blur fused with the ray collapse (fused path: only live row groups exist in memory)
-  if (drc && z_fixed(S.Kz)) {
-    const unsigned char* fl = (plan.ok && plan.sparse) ? rowflags_of(point_index, S) : nullptr;
+  // 3. z blur fused with the ray collapse
+  if (drc && z_fixed(S.Kz))
     return launch_zfwd(st, S, P, zin, taps_z, S.Kz, scale, grid_blur, nullptr, proj, proj_depth, ray_sums,
-                       clip_in, 1, fl, plan.NG, plan.GRP);
-  }
-
+                       clip_in, 1);
   // generic tap count or max-collapse: materialise G2, then collapse separately
   if (S.Kz > 0) {
     if (clip_in) return DPC_E_MODE;  // z-only blur of the raw grid is not a reference configuration
@@ -2401,7 +2281,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   if (!drc && P.collapse_mode != DPC_COLLAPSE_MAX) return DPC_E_MODE;
   if (!dproj && !(drc && dproj_depth)) return DPC_E_NULL;
   if (scale && !dscale) return DPC_E_NULL;
-  const SplatPlan plan = splat_plan(S, P);
+  const SplatPlan plan = splat_plan(S);
   const bool use_cmask = plan.ok;
   if (use_cmask ? (!clip_mask || !point_index) : !grid_raw) return DPC_E_NULL;
   if (!workspace || workspace_bytes < dpc_workspace_bytes(shape, 1) || ((uintptr_t)workspace & 255) != 0)
@@ -2418,9 +2298,8 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   float* ds_acc = scale ? accum : nullptr;
   // 1. collapse VJP (+ z-FIR adjoint) -> tA
   if (drc && z_fixed(S.Kz)) {
-    const unsigned char* fl = (use_cmask && plan.sparse) ? rowflags_of(point_index, S) : nullptr;
     rc = launch_zbwd(st, S, P, grid_blur, taps_z, S.Kz, scale, ray_sums, dproj, dproj_depth, nullptr, tA,
-                     ds_acc, 1, fl, plan.NG, plan.GRP);
+                     ds_acc, 1);
     if (rc) return rc;
   } else {
     float* first = (S.Kz > 0) ? tB : tA;

@@ -84,17 +84,11 @@ int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, 
  * (generic path: zero-fill + global float atomics); bit 1 (value 2) = clip_mask
  * [B,N,4] bytes, one bit per touched trilinear corner (fused path: points are
  * bucketed by depth cell and splatted into per-plane LDS tiles, the raw grid
- * never reaches HBM); bit 2 (value 4) = point_index, int32 [dpc_point_index_ints()]:
- * the points of each view sorted by depth cell, the bucket starts, and row-group
- * liveness flags, which the backward re-uses (set together with bit 1).  On this
- * path grid_blur holds valid data only in live row groups.  Buffers that are not
- * used may be null.  <0 on error. */
+ * never reaches HBM); bit 2 (value 4) = point_index, int32 [B*N + B*(Dz+2)]: the
+ * points of each view sorted by depth cell followed by the bucket starts, which
+ * the backward's per-plane gather re-uses (set together with bit 1).  Buffers
+ * that are not used may be null.  <0 on error. */
 int dpc_saved_layout(const DpcShape* shape, const DpcParams* params);
-
-/* Number of int32 elements of the `point_index` buffer (0 when bit 2 of dpc_saved_layout is
- * clear): [B,N] point ids sorted by depth cell | [B,Dz+2] bucket starts | row-group liveness
- * bytes of the xy-blurred grid (row groups that are exactly zero are neither stored nor read). */
-size_t dpc_point_index_ints(const DpcShape* shape, const DpcParams* params);
 
 /* Bytes of scratch `dpc_project_forward` (direction 0) / `dpc_project_backward`
  * (direction 1) need.  256-byte aligned device memory. */
