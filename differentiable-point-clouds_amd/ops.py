@@ -158,6 +158,7 @@ class ProjectFused(torch.autograd.Function):
                                      _p(point_index), _p(grid_blur), _p(logt), _p(proj), _p(depth), ws.ptr, ws.nbytes)
         lib.check(rc, "dpc_project_forward")
         ctx.meta, ctx.K = meta, K
+        ctx.set_materialize_grads(False)     # unused outputs (depth, tr_pc) arrive as None, not as zero fills
         ctx.has = (trans is not None, scale is not None, focal is not None)
         ctx.scale_shape = None if scale is None else tuple(scale.shape)
         ctx.focal_shape = None if focal is None else tuple(focal.shape)
@@ -325,6 +326,7 @@ class DrcProjection(torch.autograd.Function):
                              _p(proj), _p(probs), int(flip_h))
         lib.check(rc, "dpc_drc_fwd")
         ctx.meta, ctx.flip = meta, int(flip_h)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(vox)
         return proj, probs
 
