@@ -60,6 +60,8 @@ SIGNATURES = {
     "dpc_transform_bwd": (ctypes.c_int, [_P, _SP, _PP] + [_P] * 10),
     "dpc_voxelize_fwd": (ctypes.c_int, [_P, _SP, _P, _P]),
     "dpc_voxelize_bwd": (ctypes.c_int, [_P, _SP, _P, _P, _P]),
+    "dpc_voxelize_values_fwd": (ctypes.c_int, [_P, _SP, ctypes.c_int, _P, _P, _P]),
+    "dpc_voxelize_values_bwd": (ctypes.c_int, [_P, _SP, ctypes.c_int, _P, _P, _P, _P, _P]),
     "dpc_blur3d": (ctypes.c_int, [_P, _SP] + [_P] * 6 + [ctypes.c_int]),
     "dpc_drc_fwd": (ctypes.c_int, [_P, _SP, _PP, _P, _P, _P, ctypes.c_int]),
     "dpc_drc_bwd": (ctypes.c_int, [_P, _SP, _PP, _P, _P, _P, _P, ctypes.c_int]),

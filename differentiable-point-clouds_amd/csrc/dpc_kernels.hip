@@ -504,6 +504,83 @@ k_gather(DpcShape S, const float* __restrict__ tr_pc, const float* __restrict__ 
   dtr_pc[o + 2] = du;
 }
 
+// RGB channels (point_cloud.py:111-118): per-point values vals[b,n,c] spread with the same
+// trilinear weights into a channel-major grid [B,C,Dz,D,D] (so that the scalar blur kernels
+// apply to it as B*C views), and the VJP w.r.t. the values and the point positions.
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_scatter_vals(DpcShape S, int C, const float* __restrict__ tr_pc, const float* __restrict__ vals,
+               float* __restrict__ grid) {
+  const int b = blockIdx.x;
+  const int n = blockIdx.y * blockDim.x + threadIdx.x;
+  if (n >= S.N) return;
+  const size_t o = ((size_t)b * S.N + n) * 3;
+  const int Dz = S.Dz, D = S.D;
+  const Cell c = locate(tr_pc[o], tr_pc[o + 1], tr_pc[o + 2], Dz, D);
+  if (!c.valid) return;
+  const float wz[2] = {1.0f - c.rz, c.rz};
+  const float wy[2] = {1.0f - c.ry, c.ry};
+  const float wx[2] = {1.0f - c.rx, c.rx};
+  const size_t V = (size_t)Dz * D * D;
+  for (int ch = 0; ch < C; ++ch) {
+    const float val = vals[((size_t)b * S.N + n) * C + ch];
+    float* g = grid + ((size_t)b * C + ch) * V;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+          const int zz = c.iz + k, yy = c.iy + j, xx = c.ix + l;
+          if (zz < Dz && yy < D && xx < D) atomicAdd(g + ((size_t)zz * D + yy) * D + xx, wz[k] * wy[j] * wx[l] * val);
+        }
+  }
+}
+
+__global__ void __launch_bounds__(DPC_BLOCK)
+k_gather_vals(DpcShape S, int C, const float* __restrict__ tr_pc, const float* __restrict__ vals,
+              const float* __restrict__ dgrid, float* __restrict__ dvals, float* __restrict__ dtr_pc /*nullable*/) {
+  const int b = blockIdx.x;
+  const int n = blockIdx.y * blockDim.x + threadIdx.x;
+  if (n >= S.N) return;
+  const size_t o = ((size_t)b * S.N + n) * 3;
+  const int Dz = S.Dz, D = S.D;
+  const Cell c = locate(tr_pc[o], tr_pc[o + 1], tr_pc[o + 2], Dz, D);
+  float drz = 0.f, dry = 0.f, drx = 0.f;
+  const float wz[2] = {1.0f - c.rz, c.rz};
+  const float wy[2] = {1.0f - c.ry, c.ry};
+  const float wx[2] = {1.0f - c.rx, c.rx};
+  const size_t V = (size_t)Dz * D * D;
+  for (int ch = 0; ch < C; ++ch) {
+    float dv = 0.f;
+    if (c.valid) {
+      const float val = vals[((size_t)b * S.N + n) * C + ch];
+      const float* g = dgrid + ((size_t)b * C + ch) * V;
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int l = 0; l < 2; ++l) {
+            const int zz = c.iz + k, yy = c.iy + j, xx = c.ix + l;
+            if (zz < Dz && yy < D && xx < D) {
+              const float gg = g[((size_t)zz * D + yy) * D + xx];
+              dv += gg * wz[k] * wy[j] * wx[l];
+              const float gv = gg * val;
+              drz += gv * (k ? 1.f : -1.f) * wy[j] * wx[l];
+              dry += gv * wz[k] * (j ? 1.f : -1.f) * wx[l];
+              drx += gv * wz[k] * wy[j] * (l ? 1.f : -1.f);
+            }
+          }
+    }
+    dvals[((size_t)b * S.N + n) * C + ch] = dv;
+  }
+  if (dtr_pc) {
+    dtr_pc[o] = drz * (float)(Dz - 1);
+    dtr_pc[o + 1] = dry * (float)(D - 1);
+    dtr_pc[o + 2] = drx * (float)(D - 1);
+  }
+}
+
 // Gather (+ sparse x-blur + clip mask) + camera-transform VJP + per-instance
 // reductions.  GATHER=false: d(tr_pc) is read from dtr_in instead.
 template <bool QUAT, bool GATHER, int KC>
@@ -2113,6 +2190,31 @@ int dpc_voxelize_bwd(dpc_stream_t stream, const DpcShape* shape, const float* tr
   if (!tr_pc || !dgrid || !dtr_pc) return DPC_E_NULL;
   DPC_LAUNCH("gather", (k_gather), point_grid(*shape), dim3(DPC_BLOCK, 1, 1), 0, (hipStream_t)stream, *shape, tr_pc,
              dgrid, dtr_pc);
+  return last_error();
+}
+
+int dpc_voxelize_values_fwd(dpc_stream_t stream, const DpcShape* shape, int channels, const float* tr_pc,
+                            const float* values, float* grid) {
+  int rc = check_shape(shape, true);
+  if (rc) return rc;
+  if (!tr_pc || !values || !grid) return DPC_E_NULL;
+  if (channels <= 0 || channels > 16) return DPC_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = dpc_memset("memset_grid", grid, grid_elems(*shape) * sizeof(float) * channels, st);
+  if (e != hipSuccess) return (int)e;
+  DPC_LAUNCH("scatter_vals", (k_scatter_vals), point_grid(*shape), dim3(DPC_BLOCK, 1, 1), 0, st, *shape, channels,
+             tr_pc, values, grid);
+  return last_error();
+}
+
+int dpc_voxelize_values_bwd(dpc_stream_t stream, const DpcShape* shape, int channels, const float* tr_pc,
+                            const float* values, const float* dgrid, float* dvalues, float* dtr_pc) {
+  int rc = check_shape(shape, true);
+  if (rc) return rc;
+  if (!tr_pc || !values || !dgrid || !dvalues) return DPC_E_NULL;
+  if (channels <= 0 || channels > 16) return DPC_E_SHAPE;
+  DPC_LAUNCH("gather_vals", (k_gather_vals), point_grid(*shape), dim3(DPC_BLOCK, 1, 1), 0, (hipStream_t)stream,
+             *shape, channels, tr_pc, values, dgrid, dvalues, dtr_pc);
   return last_error();
 }
 

@@ -127,9 +127,9 @@ class ModelPointCloud(object):
         else:
             s = None
         outputs["all_scaling_factors"] = s
-        if cfg.pc_rgb:
-            raise NotImplementedError("RGB channels are SURVEY.md 8(f) scope")
-        outputs["all_rgb"] = None
+        # model_pc.py:294-297 (as in the reference, colours are replicated over views only,
+        # so pc_rgb with several pose candidates is not a supported combination)
+        outputs["all_rgb"] = self.replicate_for_multiview(outputs["rgb_1"]) if cfg.pc_rgb else None
         return outputs
 
     def compute_projection(self, inputs, outputs, is_training):   # model_pc.py:220-259

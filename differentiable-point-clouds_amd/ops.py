@@ -51,7 +51,8 @@ def _p(t):
 
 
 def _c(t):
-    return None if t is None else t.detach().contiguous()
+    # inside autograd.Function.forward/backward tensors are already outside the graph
+    return None if t is None else (t if t.is_contiguous() else t.contiguous())
 
 
 def _shape(B, N, meta, K=(0, 0, 0)):
@@ -275,6 +276,41 @@ class Voxelize(torch.autograd.Function):
         rc = lib.dpc_voxelize_bwd(_stream(lib, tr_pc), ctypes.byref(shape), _p(tr_pc), _p(dgrid), _p(dtr))
         lib.check(rc, "dpc_voxelize_bwd")
         return dtr, None, None
+
+
+class VoxelizeValues(torch.autograd.Function):
+    """RGB branch of pointcloud2voxels3d_fast (dpc/util/point_cloud.py:111-118):
+    (tr_pc [B,N,3], values [B,N,C]) -> channel-major grid [B,C,Dz,D,D]."""
+
+    @staticmethod
+    def forward(ctx, tr_pc, values, Dz, D, stop_points_gradient):
+        if values.dim() != 3 or values.shape[:2] != tr_pc.shape[:2]:
+            raise ValueError("rgb must be [B,N,C] matching the point cloud")
+        lib = _lib_for(tr_pc, values)
+        tr_pc, values = _c(tr_pc), _c(values)
+        B, N, C = values.shape
+        shape = DpcShape(B, N, int(Dz), int(D), 0, 0, 0)
+        grid = torch.empty(B, C, Dz, D, D, dtype=torch.float32, device=tr_pc.device)
+        rc = lib.dpc_voxelize_values_fwd(_stream(lib, tr_pc), ctypes.byref(shape), C, _p(tr_pc), _p(values), _p(grid))
+        lib.check(rc, "dpc_voxelize_values_fwd")
+        ctx.dims = (Dz, D, bool(stop_points_gradient))
+        ctx.save_for_backward(tr_pc, values)
+        return grid
+
+    @staticmethod
+    def backward(ctx, dgrid):
+        tr_pc, values = ctx.saved_tensors
+        lib = _lib_for(tr_pc)
+        Dz, D, stop = ctx.dims
+        B, N, C = values.shape
+        shape = DpcShape(B, N, int(Dz), int(D), 0, 0, 0)
+        dgrid = _c(dgrid)
+        dvals = torch.empty_like(values)
+        dtr = None if stop else torch.empty_like(tr_pc)
+        rc = lib.dpc_voxelize_values_bwd(_stream(lib, tr_pc), ctypes.byref(shape), C, _p(tr_pc), _p(values),
+                                         _p(dgrid), _p(dvals), _p(dtr))
+        lib.check(rc, "dpc_voxelize_values_bwd")
+        return dtr, dvals, None, None, None
 
 
 def _blur(lib, x, taps, K, order):

@@ -71,4 +71,9 @@ def drc_depth_projection(p, cfg):
 
 
 def project_volume_rgb_integral(cfg, p, rgb):
-    raise NotImplementedError("RGB integral is SURVEY.md 8(f) scope (pc_rgb is off by default)")
+    """dpc/util/drc.py:126-136: sum_i p_i rgb_i with a white background behind the grid.
+    p [Dz+1,B,D,D,1], rgb [B,Dz,D,D,3] -> [B,D,D,3] (one broadcast-multiply-reduce)."""
+    rgb = rgb.permute(1, 0, 2, 3, 4)
+    background = torch.ones_like(rgb[:1])
+    rgb_full = torch.cat([rgb, background], dim=0)
+    return (p * rgb_full).sum(dim=0)

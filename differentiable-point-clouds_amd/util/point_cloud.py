@@ -50,7 +50,8 @@ def _flat_taps(cfg, kernel, device):
         raise NotImplementedError("dense 3-D Gaussian kernel (pc_separable_gauss_filter=false)")
     taps = {"x": None, "y": None, "z": None}
     for k in kernel:
-        k = torch.as_tensor(k, dtype=torch.float32)
+        if not (isinstance(k, torch.Tensor) and k.dtype == torch.float32):
+            k = torch.as_tensor(k, dtype=torch.float32)
         if k.dim() != 5 or k.shape[3] != 1 or k.shape[4] != 1:
             raise ValueError("separable kernel filters must be [kd,kh,kw,1,1], got %s" % (tuple(k.shape),))
         kd, kh, kw = int(k.shape[0]), int(k.shape[1]), int(k.shape[2])
@@ -59,7 +60,7 @@ def _flat_taps(cfg, kernel, device):
         axis = "z" if kd > 1 else ("y" if kh > 1 else "x")
         if taps[axis] is not None:
             raise NotImplementedError("two filters along the same axis")
-        taps[axis] = k.reshape(-1).to(device)
+        taps[axis] = k.reshape(-1) if k.device == device else k.reshape(-1).to(device)
     return taps["x"], taps["y"], taps["z"]
 
 
@@ -68,13 +69,22 @@ def pc_perspective_transform(cfg, point_cloud, transform, predicted_translation=
     return ops.Transform.apply(point_cloud, transform, predicted_translation, focal_length, _meta(cfg))
 
 
+def _voxels_rgb_cm(cfg, pc, rgb):
+    """channel-major [B,3,Dz,D,D] RGB grid (point_cloud.py:111-118)."""
+    Dz, D = _dims(cfg)
+    return ops.VoxelizeValues.apply(pc, rgb, Dz, D, bool(getattr(cfg, "pc_rgb_stop_points_gradient", False)))
+
+
 def pointcloud2voxels3d_fast(cfg, pc, rgb):
     """dpc/util/point_cloud.py:60-136: trilinear scatter-add of [B,N,3] points
-    (already in the unit cube) into [B,Dz,D,D]."""
-    if rgb is not None:
-        raise NotImplementedError("RGB channels are SURVEY.md 8(f) scope (pc_rgb is off by default)")
+    (already in the unit cube) into [B,Dz,D,D]; with rgb [B,N,3] also the
+    colour grid [B,Dz,D,D,3]."""
     Dz, D = _dims(cfg)
-    return ops.Voxelize.apply(pc, Dz, D), None
+    voxels = ops.Voxelize.apply(pc, Dz, D)
+    voxels_rgb = None
+    if rgb is not None:
+        voxels_rgb = _voxels_rgb_cm(cfg, pc, rgb).permute(0, 2, 3, 4, 1)
+    return voxels, voxels_rgb
 
 
 def smoothen_voxels3d(cfg, voxels, kernel):
@@ -85,8 +95,18 @@ def smoothen_voxels3d(cfg, voxels, kernel):
     return out.unsqueeze(-1) if voxels.dim() == 5 else out
 
 
+def _convolve_cm(cfg, vox_cm, kernel):
+    """per-channel separable blur of a channel-major grid [B,C,Dz,D,D]."""
+    tx, ty, tz = _flat_taps(cfg, kernel, vox_cm.device)
+    B, C = vox_cm.shape[0], vox_cm.shape[1]
+    out = ops.Blur3d.apply(vox_cm.reshape(B * C, *vox_cm.shape[2:]), tx, ty, tz)
+    return out.reshape(vox_cm.shape)
+
+
 def convolve_rgb(cfg, voxels_rgb, kernel):
-    raise NotImplementedError("RGB channels are SURVEY.md 8(f) scope")
+    """dpc/util/point_cloud.py:148-154 on [B,Dz,D,D,3]."""
+    cm = voxels_rgb.permute(0, 4, 1, 2, 3).contiguous()
+    return _convolve_cm(cfg, cm, kernel).permute(0, 2, 3, 4, 1)
 
 
 def pointcloud2voxels(cfg, input_pc, sigma):
@@ -137,8 +157,6 @@ class ProjectionOutputs(dict):
 def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
                             all_rgb, kernel=None, scaling_factor=None, focal_length=None):
     """dpc/util/point_cloud.py:229-290."""
-    if all_rgb is not None:
-        raise NotImplementedError("RGB channels are SURVEY.md 8(f) scope (pc_rgb is off by default)")
     _drc._check_cfg(cfg)
     meta = _meta(cfg)
     tx, ty, tz = _flat_taps(cfg, kernel, point_cloud.device)
@@ -160,12 +178,32 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
     def make_probs():
         if cfg.ptn_max_projection:
             return None
-        v = make_voxels()
-        p, _ = _drc.drc_event_probabilities_impl(v, cfg, flip_h=True)   # tf.reverse(drc_probs, [2])
-        return p
+        if "probs" not in state:
+            v = make_voxels()
+            state["probs"], _ = _drc.drc_event_probabilities_impl(v, cfg, flip_h=True)   # tf.reverse(drc_probs, [2])
+        return state["probs"]
 
-    eager = {"proj": proj, "tr_pc": tr_pc, "voxels_rgb": None, "proj_rgb": None, "proj_depth": proj_depth}
-    return ProjectionOutputs(eager, make_voxels, make_probs)
+    voxels_rgb = proj_rgb = None
+    if all_rgb is not None:
+        # colour channels (point_cloud.py:244-262,275-279; off by default, pc_rgb): stage-level kernels
+        rgb_cm = _voxels_rgb_cm(cfg, tr_pc, all_rgb)                       # [B,3,Dz,D,D]
+        if kernel is not None:
+            if not cfg.pc_rgb_clip_after_conv:
+                rgb_cm = torch.clamp(rgb_cm, 0.0, 1.0)
+            rgb_cm = _convolve_cm(cfg, rgb_cm, kernel)
+        if cfg.pc_rgb_divide_by_occupancies:
+            div = ops.Voxelize.apply(tr_pc, meta.Dz, meta.D).detach()      # stop_gradient(voxels_raw)
+            div = ops.Blur3d.apply(div, tx, ty, tz)
+            rgb_cm = rgb_cm / (div.unsqueeze(1) + cfg.pc_rgb_divide_by_occupancies_epsilon)
+        if cfg.pc_rgb_clip_after_conv:
+            rgb_cm = torch.clamp(rgb_cm, 0.0, 1.0)
+        voxels_rgb = torch.flip(rgb_cm.permute(0, 2, 3, 4, 1), dims=[2])   # tf.reverse(voxels_rgb, [2])
+        probs = make_probs()
+        proj_rgb = None if probs is None else _drc.project_volume_rgb_integral(cfg, probs, voxels_rgb)
+
+    eager = {"proj": proj, "tr_pc": tr_pc, "voxels_rgb": voxels_rgb, "proj_rgb": proj_rgb, "proj_depth": proj_depth}
+    out = ProjectionOutputs(eager, make_voxels, make_probs)
+    return out
 
 
 def pc_point_dropout(points, rgb, keep_prob, generator=None):

@@ -149,6 +149,15 @@ int dpc_voxelize_fwd(dpc_stream_t stream, const DpcShape* shape, const float* tr
 int dpc_voxelize_bwd(dpc_stream_t stream, const DpcShape* shape, const float* tr_pc,
                      const float* dgrid, float* dtr_pc);
 
+/* RGB branch of pointcloud2voxels3d_fast, dpc/util/point_cloud.py:111-118: values [B,N,C]
+ * (C <= 16) are spread with the trilinear weights into a CHANNEL-MAJOR grid [B,C,Dz,D,D]
+ * (zero-filled first), so the scalar blur applies to it as B*C views.  bwd: dvalues [B,N,C]
+ * and (nullable; omit for cfg.pc_rgb_stop_points_gradient) the gradient w.r.t. the points. */
+int dpc_voxelize_values_fwd(dpc_stream_t stream, const DpcShape* shape, int channels, const float* tr_pc,
+                            const float* values, float* grid);
+int dpc_voxelize_values_bwd(dpc_stream_t stream, const DpcShape* shape, int channels, const float* tr_pc,
+                            const float* values, const float* dgrid, float* dvalues, float* dtr_pc);
+
 /* smoothen_voxels3d (separable), dpc/util/point_cloud.py:139-145.  order 0 =
  * x,y,z (gauss_kernel.py:27-32); order 1 = adjoint (z first).  The blur is
  * self-adjoint for odd symmetric taps.  tmp: one grid [B,Dz,D,D]; in != out. */

@@ -55,15 +55,15 @@ def run_reference(cfg, inp, sigma, dtype, upstream, want_grads=True, use_kernel=
     (all in the reference's output layouts)."""
     tf.set_float_dtype(dtype)
     leaves = {}
-    for k in ("pc", "pose", "trans", "scale", "focal"):
+    for k in ("pc", "pose", "trans", "scale", "focal", "rgb"):
         if inp.get(k) is not None:
             leaves[k] = torch.tensor(inp[k], dtype=dtype, requires_grad=want_grads)
     kern = ref_gk.smoothing_kernel(cfg, sigma) if use_kernel else None
     T = lambda k: tf.convert_to_tensor(leaves[k]) if k in leaves else None
-    out = ref_pc.pointcloud_project_fast(cfg, T("pc"), T("pose"), T("trans"), None, kern,
+    out = ref_pc.pointcloud_project_fast(cfg, T("pc"), T("pose"), T("trans"), T("rgb"), kern,
                                          scaling_factor=T("scale"), focal_length=T("focal"))
     res = {}
-    for k in ("proj", "voxels", "tr_pc", "drc_probs", "proj_depth"):
+    for k in ("proj", "voxels", "tr_pc", "drc_probs", "proj_depth", "voxels_rgb", "proj_rgb"):
         if out[k] is not None:
             res[k] = out[k].detach().numpy().copy()
     if kern is not None:
@@ -72,7 +72,8 @@ def run_reference(cfg, inp, sigma, dtype, upstream, want_grads=True, use_kernel=
         res["taps_z"] = kern[2].detach().numpy().reshape(-1)
     if want_grads:
         loss = 0.0
-        for name, key in (("w_proj", "proj"), ("w_depth", "proj_depth"), ("w_probs", "drc_probs")):
+        for name, key in (("w_proj", "proj"), ("w_depth", "proj_depth"), ("w_probs", "drc_probs"),
+                          ("w_projrgb", "proj_rgb")):
             if upstream.get(name) is not None:
                 loss = loss + (torch.tensor(upstream[name], dtype=dtype) * out[key]).sum()
         loss.backward()
@@ -199,6 +200,18 @@ def main():
     E[:, 3, 3] = 1.0
     inp_m = dict(pc=inp_v["pc"], pose=E.astype(np.float32), scale=inp_v["scale"])
     save("tiny_matrix", sigma=0.8, K=5, D=16, Dz=16, **inp_m, **up, **both(cfg_m, inp_m, 0.8, up))
+
+    # ---- RGB channels (pc_rgb): default switches, and divide-by-occupancy + clip-after-conv +
+    #      stop-points-gradient ----------------------------------------------------------------
+    inp_c = tiny_inputs(seed=21)
+    inp_c["rgb"] = np.random.default_rng(22).uniform(0, 1, (2, 64, 3)).astype(np.float32)
+    up_c = rand_upstream(23, 2, 16, 16, depth=False)
+    up_c["w_projrgb"] = np.random.default_rng(24).standard_normal((2, 16, 16, 3)).astype(np.float32)
+    keep = lambda g: {k: v for k, v in g.items() if not k.startswith(("voxels_f", "drc_probs"))}
+    save("tiny_rgb", sigma=0.8, K=5, D=16, Dz=16, **inp_c, **up_c, **keep(both(cfg, inp_c, 0.8, up_c)))
+    cfg_c2 = make_cfg(vox_size=16, pc_gauss_kernel_size=5, pc_rgb_divide_by_occupancies=True,
+                      pc_rgb_clip_after_conv=True, pc_rgb_stop_points_gradient=True)
+    save("tiny_rgb_div", sigma=0.8, K=5, D=16, Dz=16, **inp_c, **up_c, **keep(both(cfg_c2, inp_c, 0.8, up_c)))
 
     # ---- K=21, sigma=3 at D=32 (the shipped experiments' kernel size) ---------------
     cfg21 = make_cfg(vox_size=32, pc_gauss_kernel_size=21)

@@ -19,6 +19,9 @@ ALL_CASES = ["tiny", "tiny_probs_grad", "tiny_focal", "tiny_nokernel", "tiny_nos
              "tiny_maxproj", "tiny_voxz", "tiny_matrix", "k21", "cfg1", "mid"]
 
 
+RGB_CASES = ["tiny_rgb", "tiny_rgb_div"]      # colour channels: pinned by the goldens only (the oracles are grey)
+
+
 def load(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     return {k: z[k] for k in z.files}

@@ -123,3 +123,17 @@ def fused_path_against_numpy_oracle(dev, B, N, D, Dz, K, sigma, with_trans, with
     names = ["dpc", "dpose", "dscale"] + (["dtrans"] if with_trans else []) + (["dfocal"] if with_focal else [])
     for name, g in zip(names, grads):
         assert relerr(g.cpu().numpy().reshape(bw[name].shape), bw[name]) < TOL_GRAD, name
+
+
+def rgb_case_matches_goldens(dev, name):
+    """pc_rgb branch (point_cloud.py:111-118,244-262,275-279; drc.py:126-136) against the
+    goldens produced by the reference's own source."""
+    from helpers import load
+    from run_case import run_product
+    g = load(name)
+    res, gr = run_product(name, g, dev, grads=True)
+    assert maxabs(res["proj"], g["proj_f64"]) < TOL_PROJ
+    assert maxabs(res["proj_rgb"], g["proj_rgb_f64"]) < 5e-5
+    assert maxabs(res["voxels_rgb"], g["voxels_rgb_f64"]) < 5e-5
+    for k in ("dpc", "dpose", "dtrans", "dscale", "drgb"):
+        assert relerr(gr[k], g[k + "_f64"]) < TOL_GRAD, k

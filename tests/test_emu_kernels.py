@@ -68,3 +68,8 @@ def test_emu_nan_points_dropped(emu):
 @pytest.mark.parametrize("case", parity_cases.FUSED_CASES[:2])
 def test_emu_fused_path_against_numpy_oracle(emu, case):
     parity_cases.fused_path_against_numpy_oracle("cpu", *case)
+
+
+@pytest.mark.parametrize("name", ["tiny_rgb", "tiny_rgb_div"])
+def test_emu_rgb_channels(emu, name):
+    parity_cases.rgb_case_matches_goldens("cpu", name)

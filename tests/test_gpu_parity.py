@@ -141,6 +141,11 @@ def test_fused_path_against_numpy_oracle(case):
     parity_cases.fused_path_against_numpy_oracle("cuda", *case)
 
 
+@pytest.mark.parametrize("name", ["tiny_rgb", "tiny_rgb_div"])
+def test_rgb_channels(name):
+    parity_cases.rgb_case_matches_goldens("cuda", name)
+
+
 def test_cfg5_stress_shape_runs():
     """BASELINE configs[4]: 16000 pts -> 256^3, sigma 2.0 (reduced to B=2 here;
     bench.py --config 5 runs B=8)."""

@@ -114,8 +114,8 @@ def test_shape_and_type_errors(emu):
         dpc_amd.pointcloud_project_fast(cfg, torch.zeros(2, 5, 2), torch.ones(2, 4), None, None)
     with pytest.raises(TypeError):
         dpc_amd.pointcloud_project_fast(cfg, pc.double(), torch.ones(2, 4).double(), None, None)
-    with pytest.raises(NotImplementedError):                                   # RGB is 8(f) scope
-        dpc_amd.pointcloud_project_fast(cfg, pc, torch.ones(2, 4), None, torch.zeros(2, 5, 3))
+    with pytest.raises(ValueError):                                            # rgb must match the cloud
+        dpc_amd.pointcloud_project_fast(cfg, pc, torch.ones(2, 4), None, torch.zeros(2, 4, 3))
     cfg_m = dpc_amd.default_config(vox_size=8, pose_quaternion=False)
     with pytest.raises(ValueError, match="quaternion pose"):                  # point_cloud.py:211-213
         dpc_amd.pointcloud_project_fast(cfg_m, pc, torch.eye(4).repeat(2, 1, 1), torch.zeros(2, 3), None)
