@@ -1207,7 +1207,7 @@ k_gather_yx(DpcShape S, const float* __restrict__ dgz, const float* __restrict__
             const float* __restrict__ taps_y, float* __restrict__ parts, int SH, int nstrips) {
   DPC_DYN_SMEM(float, tin);  // [RT][D]
   constexpr int h = KC / 2;
-  constexpr int NLD = 10;    // 16-byte loads per thread and plane (host guarantees RT*D/4 <= NLD*256)
+  constexpr int NLD = 11;    // 16-byte loads per thread and plane (host guarantees RT*D/4 <= NLD*256)
   const int D = S.D, Dz = S.Dz, N = S.N;
   const int nzg = (Dz + DPC_GATHER_PZ - 1) / DPC_GATHER_PZ;
   const int bid = blockIdx.x;
@@ -2001,13 +2001,13 @@ SplatPlan splat_plan(const DpcShape& S) {
   const int nsy = DPC_BLOCK / (D / p.vy);
   if (nsy < 1 || SH % nsy != 0) return p;
   // k_gather_yx: one LDS tile of gSH + 2h rows, gRS = gSH / nsy rows per y-stream in {16, 8},
-  // at most 10 16-byte loads per thread and plane; otherwise backward uses the generic kernels
+  // at most 11 16-byte loads per thread and plane; otherwise backward uses the generic kernels
   p.gSH = 0;
   for (int rs = 16; rs >= 8; rs >>= 1) {
     const int g = rs * nsy;
     if (g > D) continue;
     const size_t rows = (size_t)g + 2 * (K / 2);
-    if (sizeof(float) * rows * D <= 48 * 1024 && rows * (D / 4) <= 10 * DPC_BLOCK) {
+    if (sizeof(float) * rows * D <= 48 * 1024 && rows * (D / 4) <= 11 * DPC_BLOCK) {
       p.gSH = g;
       p.gRS = rs;
       break;

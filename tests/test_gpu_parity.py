@@ -146,6 +146,12 @@ def test_rgb_channels(name):
     parity_cases.rgb_case_matches_goldens("cuda", name)
 
 
+def test_d256_fused_path_against_numpy_oracle():
+    """256^3 grid (BASELINE configs[4] resolution) at B=1: k_splat_xy / k_gather_yx with 32-row
+    strips and 16-byte lanes, against the float64 NumPy oracle."""
+    parity_cases.fused_path_against_numpy_oracle("cuda", 1, 3000, 256, 256, 11, 2.0, False, False)
+
+
 def test_cfg5_stress_shape_runs():
     """BASELINE configs[4]: 16000 pts -> 256^3, sigma 2.0 (reduced to B=2 here;
     bench.py --config 5 runs B=8)."""
