@@ -52,12 +52,6 @@
 
 #include <math.h>
 
-// DPC_PINGPONG=1 alternates two register buffers in the z kernels instead of
-// copying the prefetched group (A/B on MI355X: neutral; kept as a tuning switch)
-#ifndef DPC_PINGPONG
-#define DPC_PINGPONG 0
-#endif
-
 #include <mutex>
 #include <vector>
 
@@ -983,6 +977,58 @@ k_zsort(DpcShape S, DpcParams P, const float* __restrict__ pc, const float* __re
   load_pose<QUAT>(P, pose, trans, focal, b, ps);
   float* tp = tr_pc + (size_t)b * N * 3;
   const float* pp = pc + (size_t)b * N * 3;
+  // points are handled in batches of PB per thread: all PB loads are issued before the first
+  // use, and the bin of every point stays in a register for the scatter pass (one WG per view
+  // leaves the latency of each dependent trip to memory fully exposed otherwise)
+  constexpr int PB = 8;
+  if (N <= PB * nth) {
+    float p0[PB], p1[PB], p2[PB];
+    int bin[PB];
+#pragma unroll
+    for (int u = 0; u < PB; ++u) {
+      const int n = tid + u * nth;
+      const int nc = n < N ? n : N - 1;
+      p0[u] = pp[3 * nc];
+      p1[u] = pp[3 * nc + 1];
+      p2[u] = pp[3 * nc + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < PB; ++u) {
+      const int n = tid + u * nth;
+      float w, v, uu;
+      transform_point<QUAT>(ps, p0[u], p1[u], p2[u], w, v, uu);
+      const Cell c = locate(w, v, uu, Dz, D);
+      bin[u] = c.valid ? c.iz : Dz;
+      if (n < N) {
+        tp[3 * n] = w;
+        tp[3 * n + 1] = v;
+        tp[3 * n + 2] = uu;
+        atomicAdd(&hist[bin[u]], 1);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int i = 0; i <= Dz; ++i) {
+        const int cnt = hist[i];
+        hist[i] = run;
+        run += cnt;
+      }
+      hist[Dz + 1] = run;
+    }
+    __syncthreads();
+    for (int i = tid; i < Dz + 2; i += nth) zstart[(size_t)b * (Dz + 2) + i] = hist[i];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PB; ++u) {
+      const int n = tid + u * nth;
+      if (n < N) {
+        const int slot = atomicAdd(&hist[bin[u]], 1);
+        order[(size_t)b * N + slot] = n;
+      }
+    }
+    return;
+  }
   for (int n = tid; n < N; n += nth) {
     float w, v, u;
     transform_point<QUAT>(ps, pp[3 * n], pp[3 * n + 1], pp[3 * n + 2], w, v, u);
@@ -1198,7 +1244,9 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
 // plane's rows are already in flight in registers while the current plane is
 // processed.  Replaces the dense y-blur pass (read V + write V) and the
 // scattered global gather by one pass that reads dGz once (+ halo).
-#define DPC_GATHER_PZ 4
+#ifndef DPC_GATHER_PZ
+#define DPC_GATHER_PZ 1   // A/B on MI355X at cfg2 (ms): 1: 0.067, 2: 0.100, 3: 0.095, 4: 0.110, 8: 0.111
+#endif
 template <int KC, int VY, int RS>
 __global__ void __launch_bounds__(DPC_BLOCK)
 k_gather_yx(DpcShape S, const float* __restrict__ dgz, const float* __restrict__ tr_pc,
@@ -1488,16 +1536,6 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
   float bufA[G][CX], bufB[G][CX];
 #pragma unroll
   for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, u, Dz, bufA[u]);
-#if DPC_PINGPONG
-  for (int t0 = 0; t0 < T; t0 += 2 * G) {
-#pragma unroll
-    for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, t0 + G + u, Dz, bufB[u]);
-    process(bufA, t0);
-#pragma unroll
-    for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, t0 + 2 * G + u, Dz, bufA[u]);
-    process(bufB, t0 + G);
-  }
-#else
   for (int t0 = 0; t0 < T; t0 += G) {
 #pragma unroll
     for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, t0 + G + u, Dz, bufB[u]);
@@ -1507,7 +1545,6 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
 #pragma unroll
       for (int c = 0; c < CX; ++c) bufA[u][c] = bufB[u][c];
   }
-#endif
   float pl[CX], pj[CX], dp[CX];
 #pragma unroll
   for (int c = 0; c < CX; ++c) {
@@ -1647,16 +1684,6 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
     float bufA[G][CX], bufB[G][CX];
 #pragma unroll
     for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, u, Dz, bufA[u]);
-#if DPC_PINGPONG
-    for (int t0 = 0; t0 < T; t0 += 2 * G) {
-#pragma unroll
-      for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, t0 + G + u, Dz, bufB[u]);
-      process(bufA, t0);
-#pragma unroll
-      for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, t0 + 2 * G + u, Dz, bufA[u]);
-      process(bufB, t0 + G);
-    }
-#else
     for (int t0 = 0; t0 < T; t0 += G) {
 #pragma unroll
       for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, t0 + G + u, Dz, bufB[u]);
@@ -1666,7 +1693,6 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
 #pragma unroll
         for (int c = 0; c < CX; ++c) bufA[u][c] = bufB[u][c];
     }
-#endif
   }
   if (dscale) {  // uniform across the grid
     block_reduce_sum<1>(dsacc);
@@ -1994,8 +2020,11 @@ SplatPlan splat_plan(const DpcShape& S) {
   int lr_shift = 0;
   while ((4 << lr_shift) < D) ++lr_shift;
   const int nstream = (DPC_BLOCK / 64) * (64 >> lr_shift);
+#ifndef DPC_SPLAT_LDS_KB
+#define DPC_SPLAT_LDS_KB 48
+#endif
   int SH = D;
-  while (SH >= nstream && sizeof(float) * (size_t)(SH + 2 * (K / 2)) * D > 48 * 1024) SH >>= 1;
+  while (SH >= nstream && sizeof(float) * (size_t)(SH + 2 * (K / 2)) * D > DPC_SPLAT_LDS_KB * 1024) SH >>= 1;
   if (SH < nstream || SH % nstream != 0) return p;
   p.vy = (D <= 128) ? 2 : 4;              // y-phase floats per lane (k_splat_xy step 5)
   const int nsy = DPC_BLOCK / (D / p.vy);
@@ -2003,7 +2032,10 @@ SplatPlan splat_plan(const DpcShape& S) {
   // k_gather_yx: one LDS tile of gSH + 2h rows, gRS = gSH / nsy rows per y-stream in {16, 8},
   // at most 11 16-byte loads per thread and plane; otherwise backward uses the generic kernels
   p.gSH = 0;
-  for (int rs = 16; rs >= 8; rs >>= 1) {
+#ifndef DPC_GATHER_RS_MAX
+#define DPC_GATHER_RS_MAX 16
+#endif
+  for (int rs = DPC_GATHER_RS_MAX; rs >= 8; rs >>= 1) {
     const int g = rs * nsy;
     if (g > D) continue;
     const size_t rows = (size_t)g + 2 * (K / 2);

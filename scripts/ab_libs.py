@@ -40,4 +40,4 @@ for name, _ in libs:
     k = res[name]["k"]
     per = {lab: sum(v) / (rounds * 5) for lab, v in k.items()}
     print("%-24s step %.3f ms (min %.3f) | " % (name, sorted(res[name]["ms"])[len(res[name]["ms"]) // 2], min(res[name]["ms"])) +
-          " ".join("%s=%.3f" % (lab, per[lab]) for lab in sorted(per) if per[lab] > 0.02))
+          " ".join("%s=%.3f" % (lab, per[lab]) for lab in sorted(per) if per[lab] > 0.004))
