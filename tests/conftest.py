@@ -14,6 +14,13 @@ os.environ.setdefault("DPC_POISON_BUFFERS", "1")   # NaN-fill kernel buffers: un
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the suites need the in-tree native libraries; build them if this is a fresh checkout
+    # (hipcc cross-compiles gfx950 without a GPU; on the GPU box the prebuilt .so travels along)
+    import shutil
+    import subprocess
+    lib = os.path.join(ROOT, "differentiable-point-clouds_amd", "csrc", "libdpc_hip.so")
+    if not os.path.exists(lib) and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(lib)])
 
 
 def pytest_collection_modifyitems(config, items):
