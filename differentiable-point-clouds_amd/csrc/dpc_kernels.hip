@@ -40,15 +40,15 @@
 #include "dpc_hip.h"
 
 #ifdef DPC_EMU
-#include "hip_emu.h"
+#include "hip_emu.h"  // tests/hipemu: a thread-per-lane model of the HIP API used below (CPU test tier only)
 #else
 #include <hip/hip_runtime.h>
-#define DPC_LAUNCH_RAW(kernel, grid, block, smem, stream, ...) \
-  hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__)
-#define DPC_DYN_SMEM(type, name)                                             \
-  extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; \
-  type* name = reinterpret_cast<type*>(name##_raw)
 #endif
+
+// dynamic LDS of the kernel as a typed pointer (16-byte aligned base)
+#define DPC_DYN_SMEM(type, name)                     \
+  HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, name##_raw) \
+  type* name = reinterpret_cast<type*>(name##_raw)
 
 #include <math.h>
 
@@ -63,9 +63,7 @@
 namespace dpcprof {
 struct Rec {
   const char* label;
-#ifndef DPC_EMU
   hipEvent_t a, b;
-#endif
 };
 static std::mutex g_mu;
 static bool g_on = false;
@@ -75,31 +73,21 @@ static inline bool begin(const char* label, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_mu);
   Rec r;
   r.label = label;
-#ifndef DPC_EMU
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return false;
   (void)hipEventRecord(r.a, st);
-#else
-  (void)st;
-#endif
   g_recs.push_back(r);
   return true;
 }
 static inline void end(hipStream_t st) {
-#ifndef DPC_EMU
   std::lock_guard<std::mutex> lk(g_mu);
   (void)hipEventRecord(g_recs.back().b, st);
-#else
-  (void)st;
-#endif
 }
 static inline void clear() {
   std::lock_guard<std::mutex> lk(g_mu);
-#ifndef DPC_EMU
   for (auto& r : g_recs) {
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
   }
-#endif
   g_recs.clear();
 }
 }  // namespace dpcprof
@@ -107,7 +95,7 @@ static inline void clear() {
 #define DPC_LAUNCH(label, kernel, grid, block, smem, stream, ...)          \
   do {                                                                     \
     const bool prof_ = dpcprof::begin(label, stream);                      \
-    DPC_LAUNCH_RAW(kernel, grid, block, smem, stream, __VA_ARGS__);        \
+    hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);    \
     if (prof_) dpcprof::end(stream);                                       \
   } while (0)
 
@@ -129,18 +117,10 @@ namespace {
 // ---------------------------------------------------------------------------
 // clip_by_value = max(min(v, hi), lo); one v_med3_f32 on the GPU (inputs are never NaN here:
 // NaN points are dropped before the grid)
-#ifdef DPC_EMU
-__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fmaxf(fminf(v, hi), lo); }
-#else
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
-#endif
 
 // 1/x, 1 ulp (v_rcp_f32); x is in [eps, 1] here
-#ifdef DPC_EMU
-__device__ __forceinline__ float dpc_rcp(float x) { return 1.0f / x; }
-#else
 __device__ __forceinline__ float dpc_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-#endif
 
 struct Quat {
   float w, x, y, z;
@@ -2159,12 +2139,10 @@ int dpc_profile_get(int i, const char** label, float* ms) {
   if (i < 0 || i >= (int)dpcprof::g_recs.size() || !label || !ms) return DPC_E_NULL;
   *label = dpcprof::g_recs[i].label;
   *ms = 0.f;
-#ifndef DPC_EMU
   hipError_t e = hipEventSynchronize(dpcprof::g_recs[i].b);
   if (e != hipSuccess) return (int)e;
   e = hipEventElapsedTime(ms, dpcprof::g_recs[i].a, dpcprof::g_recs[i].b);
   if (e != hipSuccess) return (int)e;
-#endif
   return DPC_OK;
 }
 

@@ -167,10 +167,23 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 
-#define DPC_LAUNCH_RAW(kernel, grid, block, smem, stream, ...)                    \
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...)               \
   do {                                                                          \
     (void)(stream);                                                             \
     hipemu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); });    \
   } while (0)
 
-#define DPC_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(hipemu::g_dyn_smem)
+// HIP's own spelling of `extern __shared__ type var[];`
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::g_dyn_smem);
+
+// AMDGCN builtins used by the kernels
+static inline float __builtin_amdgcn_fmed3f(float v, float lo, float hi) { return fmaxf(fminf(v, hi), lo); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+
+// HIP events (the library's optional per-kernel timing): no-ops, elapsed time 0
+typedef int hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = 0; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
