@@ -38,8 +38,8 @@ import dpc_amd  # noqa: E402
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def build_case(cfg_id, B, device, seed_offset=0):
-    c = dpc_amd.synthetic.config_inputs(cfg_id, B=B, seed_offset=seed_offset)
+def build_case(cfg_id, B, device, seed_offset=0, kind="shell"):
+    c = dpc_amd.synthetic.config_inputs(cfg_id, B=B, kind=kind, seed_offset=seed_offset)
     cfg = dpc_amd.default_config(vox_size=c["D"], pc_gauss_kernel_size=c["K"])
     t = lambda a: torch.tensor(a, device=device, requires_grad=True)
     case = dict(cfg=cfg, pc=t(c["pc"]), pose=t(c["pose"]), scale=t(c["scale"]),
@@ -63,13 +63,16 @@ def kernel_algorithmic_bytes(label, case):
     zero-fill writes one (1 V); point kernels move O(N) bytes + their atomics."""
     V = 4 * case["D"] ** 3
     B, N = case["B"], case["N"]
-    dense = {"zfwd": 2 * V, "zbwd": 2 * V, "blur_plane": 2 * V, "blur_z": 2 * V, "memset_grid": V}
+    dense = {"zfwd": 2 * V, "zbwd": 2 * V, "blur_plane": 2 * V, "blur_xy": 2 * V, "blur_z": 2 * V, "memset_grid": V,
+             "splat_xy": V, "gather_yx": V}
     if label in dense:
         return B * dense[label]
     if label == "points_fwd":
         return B * (N * 24 + 8 * N * 8)
     if label == "points_bwd":
         return B * (N * 36 + 8 * N * 8)
+    if label == "zsort":
+        return B * N * 40
     return 0
 
 
@@ -135,6 +138,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 5])
     ap.add_argument("--batch", type=int, default=None, help="views per GPU (default: the config's)")
+    ap.add_argument("--points", default="shell", choices=["shell", "ball"],
+                    help="synthetic cloud: noisy sphere shell (surface-like, default) or uniform ball (SURVEY.md 8(d))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -148,7 +153,7 @@ def main():
     rank, world, device = dd.init("nccl")
 
     lib = dpc_amd.get_library()
-    case = build_case(args.config, args.batch, device, seed_offset=1000 * rank)
+    case = build_case(args.config, args.batch, device, seed_offset=1000 * rank, kind=args.points)
 
     for _ in range(args.warmup):
         step(case)
@@ -206,9 +211,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: pointcloud_project_fast fwd+bwd, N=%d, "
-                                   "grid %d^3, K=%d, sigma=%.1f, batch %d views per GPU, shell point clouds, "
+                                   "grid %d^3, K=%d, sigma=%.1f, batch %d views per GPU, %s point clouds, "
                                    "dproj=(proj-gt)/B" % ({1: 0, 2: 1, 5: 4}[args.config], case["N"], case["D"],
-                                                         case["K"], case["sigma"], case["B"]),
+                                                         case["K"], case["sigma"], case["B"], args.points),
                        "global_batch": world * case["B"], "K": case["K"], "parallelism": "views sharded x%d, "
                        "no data-path collective" % world},
             "roofline": roof,
