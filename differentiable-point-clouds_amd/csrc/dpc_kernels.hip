@@ -2096,6 +2096,86 @@ int launch_splat_xy(hipStream_t st, const DpcShape& S, const DpcParams& P, const
 
 }  // namespace
 
+// ===========================================================================
+// Silhouette loss epilogue (reference model_pc.py:308-337 proj_loss_pose_candidates,
+// :383-423 add_proj_loss): bilinear GT-mask resize on the fly, per-instance squared
+// error, arg-min over the C pose candidates of each (model, view) group, masked L2.
+// Three tiny launches over [B,D,D] images; proj is 0.1 % of the path's HBM traffic.
+// ===========================================================================
+// tf.image.resize_images(BILINEAR) of TF1: src = dst * (in/out), no half-pixel
+// centres, hi index clamped; S == D reads the pixel itself.
+__device__ __forceinline__ float gt_sample(const float* __restrict__ gt, int S, int D, float ratio, int y, int x) {
+  if (S == D) return gt[y * S + x];
+  const float sy = (float)y * ratio, sx = (float)x * ratio;
+  const int y0 = (int)sy, x0 = (int)sx;  // sy, sx >= 0: truncation == floor
+  const int y1 = y0 + 1 < S ? y0 + 1 : S - 1, x1 = x0 + 1 < S ? x0 + 1 : S - 1;
+  const float ly = sy - (float)y0, lx = sx - (float)x0;
+  const float tl = gt[y0 * S + x0], tr = gt[y0 * S + x1], bl = gt[y1 * S + x0], br = gt[y1 * S + x1];
+  const float top = tl + (tr - tl) * lx, bot = bl + (br - bl) * lx;
+  return top + (bot - top) * ly;
+}
+
+// one work-group per instance b = g*C + c: inst_err[b] = sum (gt_g - proj_b)^2
+__global__ void __launch_bounds__(DPC_BLOCK) k_sil_err(const float* __restrict__ proj, const float* __restrict__ gt,
+                                                       float* __restrict__ inst_err, int C, int D, int S) {
+  const int b = blockIdx.x, g = b / C;
+  const float* pb = proj + (size_t)b * D * D;
+  const float* gg = gt + (size_t)g * S * S;
+  const float ratio = (float)S / (float)D;
+  float acc[1] = {0.f};
+  for (int i = threadIdx.x; i < D * D; i += DPC_BLOCK) {
+    const int y = i / D, x = i - y * D;
+    const float d = gt_sample(gg, S, D, ratio, y, x) - pb[i];
+    acc[0] = fmaf(d, d, acc[0]);
+  }
+  block_reduce_sum<1>(acc);
+  if (threadIdx.x == 0) inst_err[b] = acc[0];
+}
+
+// single work-group: winners[g] = argmin_c inst_err[g,c] (first minimum, as tf.argmin),
+// weight[b] = [c == winner] * valid_g, loss = sum_g valid_g^2 * err[g,win] / (2 G)
+__global__ void __launch_bounds__(DPC_BLOCK) k_sil_select(const float* __restrict__ inst_err,
+                                                          const float* __restrict__ valid, int* __restrict__ winners,
+                                                          float* __restrict__ weight, float* __restrict__ loss, int G,
+                                                          int C) {
+  float acc[1] = {0.f};
+  for (int g = threadIdx.x; g < G; g += DPC_BLOCK) {
+    int win = 0;
+    float best = inst_err[(size_t)g * C];
+    for (int c = 1; c < C; ++c) {
+      const float e = inst_err[(size_t)g * C + c];
+      if (e < best) {
+        best = e;
+        win = c;
+      }
+    }
+    const float w = (valid && C > 1) ? valid[g] : 1.f;  // the C == 1 branch of add_proj_loss ignores valid_samples
+    for (int c = 0; c < C; ++c) weight[(size_t)g * C + c] = (c == win) ? w : 0.f;
+    if (winners) winners[g] = win;
+    acc[0] += w * w * best;
+  }
+  block_reduce_sum<1>(acc);
+  if (threadIdx.x == 0) loss[0] = acc[0] * 0.5f / (float)G;
+}
+
+// dproj[b] = dloss * weight_b^2 / G * (proj_b - gt_g)
+__global__ void __launch_bounds__(DPC_BLOCK) k_sil_grad(const float* __restrict__ proj, const float* __restrict__ gt,
+                                                        const float* __restrict__ weight,
+                                                        const float* __restrict__ dloss, float* __restrict__ dproj,
+                                                        int C, int D, int S, float inv_G) {
+  const int b = blockIdx.y, g = b / C;
+  const int i = blockIdx.x * DPC_BLOCK + threadIdx.x;
+  if (i >= D * D) return;
+  const float w = weight[b];
+  float out = 0.f;
+  if (w != 0.f) {
+    const int y = i / D, x = i - y * D;
+    const float d = proj[(size_t)b * D * D + i] - gt_sample(gt + (size_t)g * S * S, S, D, (float)S / (float)D, y, x);
+    out = dloss[0] * w * w * inv_G * d;
+  }
+  dproj[(size_t)b * D * D + i] = out;
+}
+
 extern "C" {
 
 const char* dpc_version(void) { return "dpc_hip 0.1.0 (gfx950)"; }
@@ -2451,6 +2531,26 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   return launch_points_bwd(st, S, P, pc, pose, trans, focal, tr_pc, dg, use_cmask ? nullptr : grid_raw,
                            use_cmask ? clip_mask : nullptr, taps_x, dtr_pc_in, nullptr, true, dpc, dpose, dtrans,
                            dfocal, scale ? dscale : nullptr, accum, false);
+}
+
+int dpc_silhouette_loss_fwd(dpc_stream_t stream, int B, int C, int D, int S, const float* proj, const float* gt,
+                            const float* valid, float* inst_err, int32_t* winners, float* weight, float* loss) {
+  if (B <= 0 || C <= 0 || B % C != 0 || D <= 0 || S < D || D > 4096) return DPC_E_SHAPE;
+  if (!proj || !gt || !inst_err || !weight || !loss) return DPC_E_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  DPC_LAUNCH("sil_err", (k_sil_err), dim3(B, 1, 1), dim3(DPC_BLOCK, 1, 1), 0, st, proj, gt, inst_err, C, D, S);
+  DPC_LAUNCH("sil_select", (k_sil_select), dim3(1, 1, 1), dim3(DPC_BLOCK, 1, 1), 0, st, (const float*)inst_err, valid,
+             (int*)winners, weight, loss, B / C, C);
+  return last_error();
+}
+
+int dpc_silhouette_loss_bwd(dpc_stream_t stream, int B, int C, int D, int S, const float* proj, const float* gt,
+                            const float* weight, const float* dloss, float* dproj) {
+  if (B <= 0 || C <= 0 || B % C != 0 || D <= 0 || S < D || D > 4096) return DPC_E_SHAPE;
+  if (!proj || !gt || !weight || !dloss || !dproj) return DPC_E_NULL;
+  DPC_LAUNCH("sil_grad", (k_sil_grad), dim3((D * D + DPC_BLOCK - 1) / DPC_BLOCK, B, 1), dim3(DPC_BLOCK, 1, 1), 0,
+             (hipStream_t)stream, proj, gt, weight, dloss, dproj, C, D, S, 1.f / (float)(B / C));
+  return last_error();
 }
 
 }  // extern "C"

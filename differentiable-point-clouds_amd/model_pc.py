@@ -14,6 +14,7 @@ import math
 
 import torch
 
+from . import ops
 from .util.gauss_kernel import smoothing_kernel
 from .util.point_cloud import pc_point_dropout, pointcloud_project_fast
 from .util.quaternion import quaternion_conjugate as q_conj
@@ -163,21 +164,14 @@ class ModelPointCloud(object):
         return outputs
 
     def proj_loss_pose_candidates(self, gt, pred, inputs):     # model_pc.py:308-337
-        """gt [B*V,S,S,1], pred [B*V*C,S,S,1] -> (loss, winning candidate [B*V])."""
+        """gt [B*V,S,S,1] (S >= pred size; resized inside the kernel), pred [B*V*C,D,D,1]
+        -> (loss, winning candidate [B*V]).  One HIP epilogue (ops.SilhouetteLoss):
+        per-instance squared error, arg-min over the C candidates, masked L2."""
         cfg = self.cfg()
-        C = cfg.pose_predict_num_candidates
-        gt = tf_repeat_0(gt, C)
-        sq_diff = (gt - pred) ** 2
-        all_loss = sq_diff.sum(dim=(1, 2, 3)).reshape(-1, C)
-        min_loss = torch.argmin(all_loss, dim=1)
-        mask = torch.nn.functional.one_hot(min_loss, C).to(pred.dtype)
-        num_samples = mask.shape[0]
-        loss_tensor = (gt - pred) * mask.reshape(-1, 1, 1, 1)
-        if cfg.variable_num_views:
-            w = tf_repeat_0(inputs["valid_samples"], C)
-            loss_tensor = loss_tensor * w.reshape(-1, 1, 1, 1)
-        proj_loss = (loss_tensor ** 2).sum() / 2 / float(num_samples)      # tf.nn.l2_loss
-        return proj_loss, min_loss
+        valid = inputs["valid_samples"] if cfg.variable_num_views else None
+        loss, min_loss, inst_err = ops.SilhouetteLoss.apply(pred, gt, valid, cfg.pose_predict_num_candidates)
+        self._last_inst_err = inst_err
+        return loss, min_loss
 
     def add_student_loss(self, inputs, outputs, min_loss, add_summary=False):    # model_pc.py:338-381
         """Distil the winning pose candidate (teacher, no gradient) into the student
@@ -199,22 +193,20 @@ class ModelPointCloud(object):
         cfg = self.cfg()
         gt = inputs["masks"]
         pred = outputs["projs"]
-        num_samples = pred.shape[0]
         gt_size, pred_size = gt.shape[1], pred.shape[1]
         assert gt_size >= pred_size, "GT size should not be higher than prediction size"
-        if gt_size > pred_size:
-            if cfg.bicubic_gt_downsampling:
-                raise NotImplementedError("bicubic GT downsampling")
-            gt = resize_images_bilinear_tf1(gt, [pred_size, pred_size])
+        if gt_size > pred_size and cfg.bicubic_gt_downsampling:
+            raise NotImplementedError("bicubic GT downsampling")
         if cfg.pc_gauss_filter_gt:
             raise NotImplementedError("Gaussian-filtered GT (off by default, default_config.yaml:93)")
         total_loss = 0
+        # the bilinear GT resize (model_pc.py:392-397) happens inside the loss kernel
         if cfg.pose_predict_num_candidates > 1:
             proj_loss, min_loss = self.proj_loss_pose_candidates(gt, pred, inputs)
             outputs["winning_pose_candidates"] = min_loss
             if cfg.pose_predictor_student:
                 total_loss = total_loss + self.add_student_loss(inputs, outputs, min_loss, add_summary)
         else:
-            proj_loss = ((gt - pred) ** 2).sum() / 2 / float(num_samples)
+            proj_loss, _, _ = ops.SilhouetteLoss.apply(pred, gt, None, 1)
         total_loss = total_loss + proj_loss
         return total_loss * weight_scale

@@ -409,3 +409,41 @@ class MaxCollapse(torch.autograd.Function):
                                       _p(dvox), ctx.flip)
         lib.check(rc, "dpc_max_collapse_bwd")
         return dvox, None
+
+
+class SilhouetteLoss(torch.autograd.Function):
+    """add_proj_loss / proj_loss_pose_candidates (dpc/models/model_pc.py:383-423, :308-337):
+    proj [B,D,D,1] against gt [B/C,S,S,1] -> (loss [], winners [B/C] int64, inst_err [B])."""
+
+    @staticmethod
+    def forward(ctx, proj, gt, valid, num_candidates):
+        lib = _lib_for(proj)
+        proj, gt = _c(proj), _c(gt)
+        B, D, C = proj.shape[0], proj.shape[1], int(num_candidates)
+        S = gt.shape[1]
+        dev = proj.device
+        if valid is not None:
+            valid = _c(valid.reshape(-1))
+        inst_err = torch.empty(B, dtype=torch.float32, device=dev)
+        weight = torch.empty(B, dtype=torch.float32, device=dev)
+        winners = torch.empty(B // C, dtype=torch.int32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        rc = lib.dpc_silhouette_loss_fwd(_stream(lib, proj), B, C, D, S, _p(proj), _p(gt), _p(valid), _p(inst_err),
+                                         _p(winners), _p(weight), _p(loss))
+        lib.check(rc, "dpc_silhouette_loss_fwd")
+        ctx.dims = (B, C, D, S)
+        ctx.save_for_backward(proj, gt, weight)
+        winners = winners.to(torch.int64)
+        ctx.mark_non_differentiable(winners, inst_err)
+        return loss, winners, inst_err
+
+    @staticmethod
+    def backward(ctx, dloss, _dwin, _derr):
+        proj, gt, weight = ctx.saved_tensors
+        lib = _lib_for(proj)
+        B, C, D, S = ctx.dims
+        dproj = torch.empty_like(proj)
+        rc = lib.dpc_silhouette_loss_bwd(_stream(lib, proj), B, C, D, S, _p(proj), _p(gt), _p(weight),
+                                         _p(_c(dloss.to(torch.float32))), _p(dproj))
+        lib.check(rc, "dpc_silhouette_loss_bwd")
+        return dproj, None, None, None

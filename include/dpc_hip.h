@@ -179,6 +179,24 @@ int dpc_max_collapse_fwd(dpc_stream_t stream, const DpcShape* shape, const float
 int dpc_max_collapse_bwd(dpc_stream_t stream, const DpcShape* shape, const float* voxels,
                          const float* dproj, float* dvoxels, int flip_h);
 
+/* Silhouette loss epilogue: replaces ModelPointCloud.add_proj_loss /
+ * proj_loss_pose_candidates (dpc/models/model_pc.py:383-423, :308-337) for the
+ * default switches (bilinear GT downsampling, no GT blur).  Instances are
+ * ordered group-major, b = g*C + c with G = B/C (model, view) groups and C pose
+ * candidates.  proj [B,D,D]; gt [G,S,S] with S >= D (resized on the fly with
+ * TF1's legacy bilinear sampling); valid [G] per-group weights
+ * (inputs["valid_samples"], cfg.variable_num_views) or NULL, ignored when
+ * C == 1 as in the reference.  Outputs: inst_err [B] = sum (gt-proj)^2,
+ * winners [G] = argmin_c (first minimum; may be NULL), weight [B] =
+ * [c == winner]*valid_g (saved for backward), loss [1] =
+ * sum_g valid_g^2 * inst_err[g, winner] / (2 G)  (tf.nn.l2_loss / num_samples).
+ * Backward: dproj [B,D,D] = dloss * weight_b^2 / G * (proj - gt). */
+int dpc_silhouette_loss_fwd(dpc_stream_t stream, int B, int C, int D, int S, const float* proj,
+                            const float* gt, const float* valid, float* inst_err, int32_t* winners,
+                            float* weight, float* loss);
+int dpc_silhouette_loss_bwd(dpc_stream_t stream, int B, int C, int D, int S, const float* proj,
+                            const float* gt, const float* weight, const float* dloss, float* dproj);
+
 #ifdef __cplusplus
 }
 #endif

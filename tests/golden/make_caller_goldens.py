@@ -75,7 +75,47 @@ def run(dtype, inp, cfg, global_step):
     return res
 
 
+def loss_cases():
+    """add_proj_loss alone (model_pc.py:383-423) on random predictions: candidate counts
+    1/2/3, non-integer GT resize ratios, per-group valid_samples weights.  -> caller_loss.npz"""
+    rng = np.random.default_rng(77)
+    out = {}
+    cases = [("c1_same", 6, 1, 16, 16, False), ("c1_resize", 4, 1, 16, 24, False), ("c2_x2", 8, 2, 16, 32, False),
+             ("c3_ratio", 12, 3, 12, 31, True), ("c4_valid", 16, 4, 8, 8, True)]
+    for name, B, C, D, S, var in cases:
+        G = B // C
+        pred = rng.uniform(0, 1, (B, D, D, 1)).astype(np.float32)
+        gt = (rng.uniform(0, 1, (G, S, S, 1)) > 0.5).astype(np.float32)
+        valid = rng.integers(0, 2, (G,)).astype(np.float32) if var else np.ones((G,), np.float32)
+        if var:
+            valid[0] = 1.0
+        cfg = make_cfg(pose_predict_num_candidates=C, variable_num_views=var, vox_size=D)
+        out[name + "_meta"] = np.array([B, C, D, S, int(var)])
+        out[name + "_pred"], out[name + "_gt"], out[name + "_valid"] = pred, gt, valid
+        for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+            tf.set_float_dtype(dt)
+            model = M.ModelPointCloud(cfg, global_step=0)
+            p = torch.tensor(pred, dtype=dt, requires_grad=True)
+            inputs = {"masks": tf.convert_to_tensor(torch.tensor(gt, dtype=dt)),
+                      "valid_samples": tf.convert_to_tensor(torch.tensor(valid, dtype=dt))}
+            outputs = {"projs": tf.convert_to_tensor(p)}
+            if C > 1:
+                g_in = inputs["masks"]
+                if S > D:
+                    g_in = tf.image.resize_images(g_in, [D, D], tf.image.ResizeMethod.BILINEAR)
+                _, win = model.proj_loss_pose_candidates(g_in, outputs["projs"], inputs)
+                out[name + "_winners"] = np.asarray(win.detach().numpy(), dtype=np.int64)
+            loss = model.add_proj_loss(inputs, outputs, 1.0, add_summary=False)
+            loss.backward()
+            out[name + "_loss_" + tag] = np.asarray(float(loss))
+            out[name + "_dpred_" + tag] = p.grad.numpy()
+        tf.set_float_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "caller_loss.npz"), names=np.array([c[0] for c in cases]), **out)
+    print("wrote caller_loss.npz", {c[0]: float(out[c[0] + "_loss_f64"]) for c in cases})
+
+
 def main():
+    loss_cases()
     rng = np.random.default_rng(2024)
     Bm, V, C, N, D = 2, 2, 2, 96, 16
     cfg = make_cfg()

@@ -137,3 +137,31 @@ def rgb_case_matches_goldens(dev, name):
     assert maxabs(res["voxels_rgb"], g["voxels_rgb_f64"]) < 5e-5
     for k in ("dpc", "dpose", "dtrans", "dscale", "drgb"):
         assert relerr(gr[k], g[k + "_f64"]) < TOL_GRAD, k
+
+
+LOSS_CASES = ["c1_same", "c1_resize", "c2_x2", "c3_ratio", "c4_valid"]
+
+
+def silhouette_loss_matches_reference(dev, name):
+    """Loss epilogue (model_pc.py:308-337,383-423) against goldens produced by the reference's
+    own add_proj_loss: loss value, winning candidates (exact), gradient wrt the projections."""
+    import dpc_amd
+    from dpc_amd import model_pc as M
+    from helpers import load
+    g = load("caller_loss")
+    B, C, D, S, var = (int(v) for v in g[name + "_meta"])
+    cfg = dpc_amd.default_config(vox_size=D, pose_predict_num_candidates=C, variable_num_views=bool(var),
+                                 pose_predictor_student=False)
+    model = M.ModelPointCloud(cfg, global_step=0, device=dev)
+    pred = torch.tensor(g[name + "_pred"], device=dev, requires_grad=True)
+    inputs = {"masks": torch.tensor(g[name + "_gt"], device=dev),
+              "valid_samples": torch.tensor(g[name + "_valid"], device=dev)}
+    outputs = {"projs": pred}
+    loss = model.add_proj_loss(inputs, outputs, 1.0)
+    (3.0 * loss).backward()                                   # non-unit upstream gradient
+    ref = float(g[name + "_loss_f64"])
+    assert abs(float(loss) - ref) < 2e-6 * max(ref, 1.0), (float(loss), ref)
+    assert relerr(pred.grad.cpu().numpy() / 3.0, g[name + "_dpred_f64"]) < 1e-5
+    if C > 1:
+        assert np.array_equal(outputs["winning_pose_candidates"].cpu().numpy(), g[name + "_winners"])
+        assert outputs["winning_pose_candidates"].dtype == torch.int64

@@ -73,3 +73,9 @@ def test_emu_fused_path_against_numpy_oracle(emu, case):
 @pytest.mark.parametrize("name", ["tiny_rgb", "tiny_rgb_div"])
 def test_emu_rgb_channels(emu, name):
     parity_cases.rgb_case_matches_goldens("cpu", name)
+
+
+@pytest.mark.parametrize("name", parity_cases.LOSS_CASES)
+def test_emu_silhouette_loss(emu, name):
+    parity_cases.silhouette_loss_matches_reference("cpu", name)
+

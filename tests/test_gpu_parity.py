@@ -146,6 +146,11 @@ def test_rgb_channels(name):
     parity_cases.rgb_case_matches_goldens("cuda", name)
 
 
+@pytest.mark.parametrize("name", parity_cases.LOSS_CASES)
+def test_silhouette_loss(name):
+    parity_cases.silhouette_loss_matches_reference("cuda", name)
+
+
 def test_d256_fused_path_against_numpy_oracle():
     """256^3 grid (BASELINE configs[4] resolution) at B=1: k_splat_xy / k_gather_yx with 32-row
     strips and 16-byte lanes, against the float64 NumPy oracle."""

@@ -64,6 +64,10 @@ def test_c_abi_argument_validation_without_gpu():
     assert rc == -2                                      # DPC_E_SHAPE
     rc = lib.dpc_blur3d(null, ctypes.byref(_capi.DpcShape(1, 1, 8, 8, 0, 0, 65)), null, null, null, null, null, null, 0)
     assert rc == -3                                      # DPC_E_TAPS
+    assert lib.dpc_silhouette_loss_fwd(null, 6, 4, 8, 8, *([null] * 7)) == -2     # B not a multiple of C
+    assert lib.dpc_silhouette_loss_fwd(null, 8, 4, 8, 4, *([null] * 7)) == -2     # GT smaller than the prediction
+    assert lib.dpc_silhouette_loss_fwd(null, 8, 4, 8, 8, *([null] * 7)) == -1
+    assert lib.dpc_silhouette_loss_bwd(null, 8, 4, 8, 8, *([null] * 5)) == -1
     with pytest.raises(_capi.DpcError):
         lib.check(-4, "x")
 
