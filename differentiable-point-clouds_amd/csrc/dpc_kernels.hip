@@ -2176,6 +2176,68 @@ __global__ void __launch_bounds__(DPC_BLOCK) k_sil_grad(const float* __restrict_
   dproj[(size_t)b * D * D + i] = out;
 }
 
+// ===========================================================================
+// Nearest-neighbour distance (reference util/point_cloud_distance.py:26-39, the Chamfer
+// evaluation of run/eval_chamfer.py:18-34): for every source point the closest target
+// point, in the tensor's own precision (fp64 in the evaluation).  Brute force, targets
+// streamed through LDS; a work-group is 64 sources x 4 target phases (wave w takes every
+// 4th target), merged lexicographically on (distance, index) so the result is tf.argmin's
+// first minimum of sqrt(sum diff^2) exactly.
+// ===========================================================================
+#define DPC_NN_CHUNK 1024
+template <typename T>
+__global__ void __launch_bounds__(256) k_nn_distance(const T* __restrict__ vs, const T* __restrict__ vt, int ns, int nt,
+                                                     T* __restrict__ proj, T* __restrict__ min_dist,
+                                                     int* __restrict__ idx) {
+  __shared__ T tile[DPC_NN_CHUNK * 3];
+  __shared__ T m_s[256];
+  __shared__ int m_i[256];
+  const int tid = threadIdx.x, lane = tid & 63, phase = tid >> 6;
+  const int s = blockIdx.x * 64 + lane;
+  const int sc = s < ns ? s : ns - 1;
+  const T sx = vs[(size_t)sc * 3], sy = vs[(size_t)sc * 3 + 1], sz = vs[(size_t)sc * 3 + 2];
+  T best_d2 = (T)INFINITY, best_s = (T)INFINITY;
+  int best_i = 0;
+  for (int base = 0; base < nt; base += DPC_NN_CHUNK) {
+    const int cnt = nt - base < DPC_NN_CHUNK ? nt - base : DPC_NN_CHUNK;
+    __syncthreads();
+    for (int i = tid; i < cnt * 3; i += 256) tile[i] = vt[(size_t)base * 3 + i];
+    __syncthreads();
+    for (int j = phase; j < cnt; j += 4) {
+#pragma clang fp contract(off)
+      // (vt - vs)^2 summed x, y, z in this order without FMA contraction, as tf.reduce_sum(diff**2, axis=2) does
+      const T dx = tile[j * 3] - sx, dy = tile[j * 3 + 1] - sy, dz = tile[j * 3 + 2] - sz;
+      const T d2 = (dx * dx + dy * dy) + dz * dz;
+      if (d2 < best_d2) {          // sqrt is monotone: only a smaller d2 can give a smaller distance
+        best_d2 = d2;
+        const T sd = sqrt(d2);
+        if (sd < best_s) {         // equal after rounding: the earlier index stays (first minimum)
+          best_s = sd;
+          best_i = base + j;
+        }
+      }
+    }
+  }
+  m_s[tid] = best_s;
+  m_i[tid] = best_i;
+  __syncthreads();
+  if (phase == 0 && s < ns) {
+    for (int w = 1; w < 4; ++w) {
+      const T os = m_s[w * 64 + lane];
+      const int oi = m_i[w * 64 + lane];
+      if (os < best_s || (os == best_s && oi < best_i)) {
+        best_s = os;
+        best_i = oi;
+      }
+    }
+    min_dist[s] = best_s;
+    idx[s] = best_i;
+    proj[(size_t)s * 3] = vt[(size_t)best_i * 3];
+    proj[(size_t)s * 3 + 1] = vt[(size_t)best_i * 3 + 1];
+    proj[(size_t)s * 3 + 2] = vt[(size_t)best_i * 3 + 2];
+  }
+}
+
 extern "C" {
 
 const char* dpc_version(void) { return "dpc_hip 0.1.0 (gfx950)"; }
@@ -2550,6 +2612,22 @@ int dpc_silhouette_loss_bwd(dpc_stream_t stream, int B, int C, int D, int S, con
   if (!proj || !gt || !weight || !dloss || !dproj) return DPC_E_NULL;
   DPC_LAUNCH("sil_grad", (k_sil_grad), dim3((D * D + DPC_BLOCK - 1) / DPC_BLOCK, B, 1), dim3(DPC_BLOCK, 1, 1), 0,
              (hipStream_t)stream, proj, gt, weight, dloss, dproj, C, D, S, 1.f / (float)(B / C));
+  return last_error();
+}
+
+int dpc_nn_distance(dpc_stream_t stream, int dtype_bytes, int ns, int nt, const void* vs, const void* vt, void* proj,
+                    void* min_dist, int32_t* idx) {
+  if (ns <= 0 || nt <= 0) return DPC_E_SHAPE;
+  if (dtype_bytes != 4 && dtype_bytes != 8) return DPC_E_MODE;
+  if (!vs || !vt || !proj || !min_dist || !idx) return DPC_E_NULL;
+  const dim3 grid((ns + 63) / 64, 1, 1), block(256, 1, 1);
+  if (dtype_bytes == 8) {
+    DPC_LAUNCH("nn_distance_f64", (k_nn_distance<double>), grid, block, 0, (hipStream_t)stream, (const double*)vs,
+               (const double*)vt, ns, nt, (double*)proj, (double*)min_dist, (int*)idx);
+  } else {
+    DPC_LAUNCH("nn_distance_f32", (k_nn_distance<float>), grid, block, 0, (hipStream_t)stream, (const float*)vs,
+               (const float*)vt, ns, nt, (float*)proj, (float*)min_dist, (int*)idx);
+  }
   return last_error();
 }
 

@@ -20,15 +20,16 @@ ProjMeta = collections.namedtuple(
 # ---------------------------------------------------------------------------
 # helpers
 # ---------------------------------------------------------------------------
-def _lib_for(*tensors):
+def _lib_for(*tensors, dtypes=(torch.float32,)):
     lib = _capi.get_library()
     for t in tensors:
         if t is None:
             continue
         if not isinstance(t, torch.Tensor):
             raise TypeError("expected a torch.Tensor, got %r" % type(t))
-        if t.dtype != torch.float32:
-            raise TypeError("the projector computes in float32; got %s" % t.dtype)
+        if t.dtype not in dtypes:
+            raise TypeError("the projector computes in float32; got %s" % t.dtype if len(dtypes) == 1 else
+                            "expected one of %s, got %s" % (dtypes, t.dtype))
         if lib.host_memory:
             if t.is_cuda:
                 raise ValueError("emulation library needs host tensors")
@@ -447,3 +448,41 @@ class SilhouetteLoss(torch.autograd.Function):
                                          _p(_c(dloss.to(torch.float32))), _p(dproj))
         lib.check(rc, "dpc_silhouette_loss_bwd")
         return dproj, None, None, None
+
+
+class NNDistance(torch.autograd.Function):
+    """point_cloud_distance (dpc/util/point_cloud_distance.py:26-39): Vs [Ns,3], Vt [Nt,3]
+    (float32 or float64) -> (proj [Ns,3] = Vt[idx], minDist [Ns], idx [Ns] int32)."""
+
+    @staticmethod
+    def forward(ctx, vs, vt):
+        lib = _lib_for(vs, vt, dtypes=(torch.float32, torch.float64))
+        if vs.dtype != vt.dtype:
+            raise TypeError("Vs and Vt must share a dtype, got %s and %s" % (vs.dtype, vt.dtype))
+        vs, vt = _c(vs), _c(vt)
+        ns, nt = vs.shape[0], vt.shape[0]
+        proj = torch.empty(ns, 3, dtype=vs.dtype, device=vs.device)
+        dist = torch.empty(ns, dtype=vs.dtype, device=vs.device)
+        idx = torch.empty(ns, dtype=torch.int32, device=vs.device)
+        rc = lib.dpc_nn_distance(_stream(lib, vs), vs.element_size(), ns, nt, _p(vs), _p(vt), _p(proj), _p(dist),
+                                 _p(idx))
+        lib.check(rc, "dpc_nn_distance")
+        ctx.save_for_backward(vs, vt, proj, dist, idx)
+        ctx.mark_non_differentiable(idx)
+        return proj, dist, idx
+
+    @staticmethod
+    def backward(ctx, dproj, ddist, _didx):
+        # what TF autodiff gives through gather_nd / sqrt(reduce_sum(diff^2)): tiny [Ns,3] torch glue
+        vs, vt, proj, dist, idx = ctx.saved_tensors
+        dvs = torch.zeros_like(vs)
+        dsel = torch.zeros_like(proj)
+        if dproj is not None:
+            dsel = dsel + dproj
+        if ddist is not None:
+            unit = (proj - vs) / dist.unsqueeze(1)            # d dist / d vt[idx]; inf/nan at dist == 0, as in TF
+            dsel = dsel + ddist.unsqueeze(1) * unit
+            dvs = dvs - ddist.unsqueeze(1) * unit
+        dvt = torch.zeros_like(vt).index_add_(0, idx.to(torch.int64), dsel)
+        return dvs, dvt
+

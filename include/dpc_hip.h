@@ -197,6 +197,16 @@ int dpc_silhouette_loss_fwd(dpc_stream_t stream, int B, int C, int D, int S, con
 int dpc_silhouette_loss_bwd(dpc_stream_t stream, int B, int C, int D, int S, const float* proj,
                             const float* gt, const float* weight, const float* dloss, float* dproj);
 
+/* Nearest-neighbour distance: replaces point_cloud_distance
+ * (dpc/util/point_cloud_distance.py:26-39), the kernel of the Chamfer evaluation
+ * (dpc/run/eval_chamfer.py:18-34, fp64 there).  vs [ns,3], vt [nt,3] in the
+ * given precision (dtype_bytes 4 = float, 8 = double).  For every source point:
+ * idx [ns] = argmin_j sqrt(sum (vt_j - vs)^2) (first minimum), min_dist [ns] that
+ * distance, proj [ns,3] = vt[idx].  No chunking needed (the reference splits the
+ * sources 10 ways only to bound its [ns,nt,3] intermediate). */
+int dpc_nn_distance(dpc_stream_t stream, int dtype_bytes, int ns, int nt, const void* vs,
+                    const void* vt, void* proj, void* min_dist, int32_t* idx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -395,6 +395,10 @@ def to_float(x):
     return _wrap(_t(x).to(_FLOAT) if isinstance(x, _torch.Tensor) else _torch.tensor(float(x), dtype=_FLOAT))
 
 
+def to_int32(x):
+    return _wrap(_t(x).to(_torch.int32))
+
+
 def argmin(x, axis=None):
     return _wrap(_torch.argmin(x, dim=axis))
 

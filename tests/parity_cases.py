@@ -165,3 +165,42 @@ def silhouette_loss_matches_reference(dev, name):
     if C > 1:
         assert np.array_equal(outputs["winning_pose_candidates"].cpu().numpy(), g[name + "_winners"])
         assert outputs["winning_pose_candidates"].dtype == torch.int64
+
+
+NN_CASES = [(n, t) for n in ("rand", "ties", "one_target", "small_src") for t in ("f64", "f32")]
+
+
+def nn_distance_matches_reference(dev, name, tag):
+    """point_cloud_distance (point_cloud_distance.py:26-39) against goldens from the reference's own
+    source: indices and projections bit-exact (first minimum on ties); distances to 1 ulp (the
+    summation order of reduce_sum over the 3 components is the backend's choice)."""
+    from dpc_amd.util.point_cloud_distance import chamfer_distance, point_cloud_distance
+    from helpers import load
+    g = load("nn_distance")
+    vs = torch.tensor(g["%s_vs_%s" % (name, tag)], device=dev)
+    vt = torch.tensor(g["%s_vt_%s" % (name, tag)], device=dev)
+    proj, dist, idx = point_cloud_distance(vs, vt)
+    assert idx.dtype == torch.int32 and dist.dtype == vs.dtype
+    assert np.array_equal(idx.cpu().numpy(), g["%s_idx_%s" % (name, tag)])
+    assert np.array_equal(proj.cpu().numpy(), g["%s_proj_%s" % (name, tag)])
+    ref = g["%s_dist_%s" % (name, tag)]
+    assert np.all(np.abs(dist.cpu().numpy() - ref) <= np.spacing(ref))
+    a, b = chamfer_distance(vs, vt)
+    assert abs(float(a) - g["%s_dist_%s" % (name, tag)].astype(np.float64).mean()) < 1e-6
+
+
+def nn_distance_gradient(dev):
+    """Gradient of sum(minDist) + <w, proj> equals torch autograd through an explicit gather."""
+    from dpc_amd.util.point_cloud_distance import point_cloud_distance
+    gen = torch.Generator().manual_seed(5)
+    vs = torch.rand(90, 3, generator=gen, dtype=torch.float64).to(dev).requires_grad_(True)
+    vt = torch.rand(130, 3, generator=gen, dtype=torch.float64).to(dev).requires_grad_(True)
+    w = torch.rand(90, 3, generator=gen, dtype=torch.float64).to(dev)
+    proj, dist, idx = point_cloud_distance(vs, vt)
+    (dist.sum() + (w * proj).sum()).backward()
+    g_vs, g_vt = vs.grad.clone(), vt.grad.clone()
+    vs.grad = vt.grad = None
+    sel = vt[idx.to(torch.int64)]
+    ((sel - vs).pow(2).sum(1).sqrt().sum() + (w * sel).sum()).backward()
+    assert maxabs(g_vs.cpu().numpy(), vs.grad.cpu().numpy()) < 1e-12
+    assert maxabs(g_vt.cpu().numpy(), vt.grad.cpu().numpy()) < 1e-12

@@ -79,3 +79,12 @@ def test_emu_rgb_channels(emu, name):
 def test_emu_silhouette_loss(emu, name):
     parity_cases.silhouette_loss_matches_reference("cpu", name)
 
+
+@pytest.mark.parametrize("name,tag", parity_cases.NN_CASES)
+def test_emu_nn_distance(emu, name, tag):
+    parity_cases.nn_distance_matches_reference("cpu", name, tag)
+
+
+def test_emu_nn_distance_gradient(emu):
+    parity_cases.nn_distance_gradient("cpu")
+

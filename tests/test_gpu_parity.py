@@ -151,6 +151,24 @@ def test_silhouette_loss(name):
     parity_cases.silhouette_loss_matches_reference("cuda", name)
 
 
+@pytest.mark.parametrize("name,tag", parity_cases.NN_CASES)
+def test_nn_distance(name, tag):
+    parity_cases.nn_distance_matches_reference("cuda", name, tag)
+
+
+def test_nn_distance_gradient_and_brute_force_at_scale():
+    parity_cases.nn_distance_gradient("cuda")
+    from dpc_amd.util.point_cloud_distance import point_cloud_distance
+    gen = torch.Generator().manual_seed(9)
+    vs = torch.rand(8000, 3, generator=gen, dtype=torch.float64).cuda()
+    vt = torch.rand(30000, 3, generator=gen, dtype=torch.float64).cuda()
+    proj, dist, idx = point_cloud_distance(vs, vt)
+    ref = torch.cdist(vs, vt).min(dim=1)                     # evaluation-scale cross-check (different rounding)
+    assert float((dist - ref.values).abs().max()) < 1e-9
+    assert float((idx.to(torch.int64) != ref.indices).float().mean()) < 1e-3
+    assert torch.equal(proj, vt[idx.to(torch.int64)])
+
+
 def test_d256_fused_path_against_numpy_oracle():
     """256^3 grid (BASELINE configs[4] resolution) at B=1: k_splat_xy / k_gather_yx with 32-row
     strips and 16-byte lanes, against the float64 NumPy oracle."""
