@@ -70,6 +70,10 @@ SIGNATURES = {
     "dpc_silhouette_loss_fwd": (ctypes.c_int, [_P] + [ctypes.c_int] * 4 + [_P] * 7),
     "dpc_silhouette_loss_bwd": (ctypes.c_int, [_P] + [ctypes.c_int] * 4 + [_P] * 5),
     "dpc_nn_distance": (ctypes.c_int, [_P] + [ctypes.c_int] * 3 + [_P] * 5),
+    "dpc_gauss_voxelize_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "dpc_gauss_voxelize_fwd": (ctypes.c_int, [_P] + [ctypes.c_int] * 3 + [_P, ctypes.c_float, ctypes.c_int] + [_P] * 4),
+    "dpc_gauss_voxelize_bwd": (ctypes.c_int, [_P] + [ctypes.c_int] * 3 + [_P, ctypes.c_float, ctypes.c_int] + [_P] * 5
+                               + [ctypes.c_size_t]),
 }
 
 

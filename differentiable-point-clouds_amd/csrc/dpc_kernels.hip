@@ -2238,6 +2238,191 @@ __global__ void __launch_bounds__(256) k_nn_distance(const T* __restrict__ vs, c
   }
 }
 
+// ===========================================================================
+// Exact Gaussian voxeliser (reference pointcloud2voxels, point_cloud.py:17-57, the
+// pc_fast:false path of pointcloud_project :219-226): every point adds
+// exp(-|p - g|^2 / 2 sigma^2) to EVERY node g of a G^3 lattice spanning [-1,1]^3.
+// O(N G^3) per view, so it is a cross-check / debugging path, not the training path.
+// The Gaussian factorises, out[a0,a1,a2] = sum_n f0[n,a0] f1[n,a1] f2[n,a2], which is
+// what both kernels use: 3 exp per (point, node line) instead of one per (point, node).
+//   f_a[n,i] = exp(-(c_a[n] - r_i)^2 / 2 sigma^2) * inv_norm_a[n],   r_i = -1 + 2i/(G-1)
+// inv_norm: 1 (no normalisation / analytical constant folded into `scale`) or
+// 1 / sum_i exp(..) per axis (cfg.pc_normalise_gauss: the reference's sum over the
+// whole lattice is the product of the three per-axis sums).
+// Output axis a takes point component perm[a].
+// ===========================================================================
+#define DPC_GV_TILE 64   // (a1, a2) tile edge of the forward kernel
+#define DPC_GV_NC 64     // points per LDS chunk
+__device__ __forceinline__ float gv_node(int i, float step) { return -1.f + (float)i * step; }
+
+// per-point inverse normalisers (cfg.pc_normalise_gauss): inv_norm[b,n,a] = 1 / sum_i exp(-(c_a - r_i)^2 k)
+__global__ void __launch_bounds__(DPC_BLOCK) k_gv_norm(const float* __restrict__ pc, float* __restrict__ inv_norm,
+                                                       int total, int G, float k, float step) {
+  const int i = blockIdx.x * DPC_BLOCK + threadIdx.x;
+  if (i >= total) return;
+  const float c = pc[i];
+  float s = 0.f;
+  for (int j = 0; j < G; ++j) {
+    const float d = c - gv_node(j, step);
+    s += expf(-d * d * k);
+  }
+  inv_norm[i] = 1.f / s;
+}
+
+// grid (B, G, tiles): one work-group = one a0 slice x a 64x64 (a1,a2) tile, each thread a 4x4 register block.
+__global__ void __launch_bounds__(256) k_gv_fwd(const float* __restrict__ pc, const float* __restrict__ inv_norm,
+                                                float* __restrict__ raw, float* __restrict__ vox, int N, int G,
+                                                int p0, int p1, int p2, float k, float scale, float step) {
+  __shared__ float F0[DPC_GV_NC];
+  __shared__ __attribute__((aligned(16))) float F1[DPC_GV_NC][DPC_GV_TILE];
+  __shared__ __attribute__((aligned(16))) float F2[DPC_GV_NC][DPC_GV_TILE];
+  const int b = blockIdx.x, a0 = blockIdx.y;
+  const int nt = (G + DPC_GV_TILE - 1) / DPC_GV_TILE;
+  const int t1 = (blockIdx.z / nt) * DPC_GV_TILE, t2 = (blockIdx.z % nt) * DPC_GV_TILE;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const float r0 = gv_node(a0, step);
+  const float* pb = pc + (size_t)b * N * 3;
+  const float* nb = inv_norm ? inv_norm + (size_t)b * N * 3 : nullptr;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+  for (int base = 0; base < N; base += DPC_GV_NC) {
+    __syncthreads();
+    if (tid < DPC_GV_NC) {
+      const int n = base + tid;
+      float f = 0.f;
+      if (n < N) {
+        const float d = pb[n * 3 + p0] - r0;
+        f = expf(-d * d * k) * scale * (nb ? nb[n * 3 + p0] : 1.f);
+      }
+      F0[tid] = f;
+    }
+    __syncthreads();
+    for (int q = tid; q < DPC_GV_NC * 2 * DPC_GV_TILE; q += 256) {
+      const int n = q / (2 * DPC_GV_TILE), r = q % (2 * DPC_GV_TILE);
+      const int second = r >= DPC_GV_TILE, col = r & (DPC_GV_TILE - 1);
+      const int node = (second ? t2 : t1) + col, comp = second ? p2 : p1;
+      float f = 0.f;
+      if (base + n < N && node < G) {
+        const float d = pb[(base + n) * 3 + comp] - gv_node(node, step);
+        f = expf(-d * d * k) * (nb ? nb[(base + n) * 3 + comp] : 1.f);
+      }
+      if (second) F2[n][col] = f;
+      else F1[n][col] = f * F0[n];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int n = 0; n < DPC_GV_NC; ++n) {
+      const float4 u = *(const float4*)&F1[n][ty * 4];
+      const float4 v = *(const float4*)&F2[n][tx * 4];
+      const float uu[4] = {u.x, u.y, u.z, u.w}, vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(uu[i], vv[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int a1 = t1 + ty * 4 + i;
+    if (a1 >= G) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int a2 = t2 + tx * 4 + j;
+      if (a2 >= G) continue;
+      const size_t o = (((size_t)b * G + a0) * G + a1) * G + a2;
+      raw[o] = acc[i][j];
+      vox[o] = clampf(acc[i][j], 0.f, 1.f);
+    }
+  }
+}
+
+// gm = dvox * [0 <= raw <= 1] (closed interval, as everywhere); zero the read-ahead pad behind the tensor
+__global__ void __launch_bounds__(DPC_BLOCK) k_gv_mask(const float* __restrict__ raw, const float* __restrict__ dvox,
+                                                       float* __restrict__ gm, size_t total, int pad) {
+  const size_t i = (size_t)blockIdx.x * DPC_BLOCK + threadIdx.x;
+  if (i < total) {
+    const float r = raw[i];
+    gm[i] = (r >= 0.f && r <= 1.f) ? dvox[i] : 0.f;
+  } else if (i < total + pad) {
+    gm[i] = 0.f;
+  }
+}
+
+// one thread per point, one wave per work-group: the masked gradient rows are wave-uniform reads.
+//   d c_a = scale * sum g * df_a * f_b * f_c,   df_a[i] = f_a[i] * ((r_i - c_a)/sigma^2 - q_a)
+// q_a = S'_a / S_a under per-point normalisation (quotient rule), else 0.
+#define DPC_GV_KC 32   // a2 nodes held in registers at a time
+__global__ void __launch_bounds__(64) k_gv_bwd(const float* __restrict__ pc, const float* __restrict__ gm,
+                                               float* __restrict__ dpc, int N, int G, int p0, int p1, int p2, float k,
+                                               float scale, float step, int normalise) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * 64 + threadIdx.x;
+  const int nc = n < N ? n : N - 1;
+  const float* pp = pc + ((size_t)b * N + nc) * 3;
+  const float c0 = pp[p0], c1 = pp[p1], c2 = pp[p2];
+  const float is2 = 2.f * k;  // 1 / sigma^2
+  float inv0 = 1.f, inv1 = 1.f, inv2 = 1.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
+  if (normalise) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, e0 = 0.f, e1 = 0.f, e2 = 0.f;
+    for (int i = 0; i < G; ++i) {
+      const float r = gv_node(i, step);
+      const float x0 = expf(-(c0 - r) * (c0 - r) * k), x1 = expf(-(c1 - r) * (c1 - r) * k),
+                  x2 = expf(-(c2 - r) * (c2 - r) * k);
+      s0 += x0; s1 += x1; s2 += x2;
+      e0 = fmaf(x0, (r - c0) * is2, e0); e1 = fmaf(x1, (r - c1) * is2, e1); e2 = fmaf(x2, (r - c2) * is2, e2);
+    }
+    inv0 = 1.f / s0; inv1 = 1.f / s1; inv2 = 1.f / s2;
+    q0 = e0 * inv0; q1 = e1 * inv1; q2 = e2 * inv2;
+  }
+  float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+  const float* gb = gm + (size_t)b * G * G * G;
+  for (int kb = 0; kb < G; kb += DPC_GV_KC) {
+    float f2[DPC_GV_KC], g2[DPC_GV_KC];
+#pragma unroll
+    for (int j = 0; j < DPC_GV_KC; ++j) {
+      const float r = gv_node(kb + j, step);
+      const float f = (kb + j < G) ? expf(-(c2 - r) * (c2 - r) * k) * inv2 : 0.f;
+      f2[j] = f;
+      g2[j] = f * ((r - c2) * is2 - q2);
+    }
+    for (int a0 = 0; a0 < G; ++a0) {
+      const float r0 = gv_node(a0, step);
+      const float f0 = expf(-(c0 - r0) * (c0 - r0) * k) * inv0;
+      const float g0 = f0 * ((r0 - c0) * is2 - q0);
+      float s = 0.f, s1 = 0.f, s2 = 0.f;
+      for (int a1 = 0; a1 < G; ++a1) {
+        const float* row = gb + ((size_t)a0 * G + a1) * G + kb;   // wave-uniform address
+        float u = 0.f, u2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < DPC_GV_KC; ++j) {
+          const float g = row[j];
+          u = fmaf(f2[j], g, u);
+          u2 = fmaf(g2[j], g, u2);
+        }
+        const float r1 = gv_node(a1, step);
+        const float f1 = expf(-(c1 - r1) * (c1 - r1) * k) * inv1;
+        const float g1 = f1 * ((r1 - c1) * is2 - q1);
+        s = fmaf(f1, u, s);
+        s1 = fmaf(g1, u, s1);
+        s2 = fmaf(f1, u2, s2);
+      }
+      d0 = fmaf(g0, s, d0);
+      d1 = fmaf(f0, s1, d1);
+      d2 = fmaf(f0, s2, d2);
+    }
+  }
+  if (n < N) {
+    float* o = dpc + ((size_t)b * N + n) * 3;
+    o[p0] = d0 * scale;
+    o[p1] = d1 * scale;
+    o[p2] = d2 * scale;
+  }
+}
+
 extern "C" {
 
 const char* dpc_version(void) { return "dpc_hip 0.1.0 (gfx950)"; }
@@ -2628,6 +2813,67 @@ int dpc_nn_distance(dpc_stream_t stream, int dtype_bytes, int ns, int nt, const 
     DPC_LAUNCH("nn_distance_f32", (k_nn_distance<float>), grid, block, 0, (hipStream_t)stream, (const float*)vs,
                (const float*)vt, ns, nt, (float*)proj, (float*)min_dist, (int*)idx);
   }
+  return last_error();
+}
+
+static int gv_args(int B, int N, int G, const int* perm, float sigma, int normalise, float* k, float* scale,
+                   float* step) {
+  if (B <= 0 || N <= 0 || G <= 0 || G > 512 || !(sigma > 0.f)) return DPC_E_SHAPE;
+  if (!perm) return DPC_E_NULL;
+  if (perm[0] < 0 || perm[0] > 2 || perm[1] < 0 || perm[1] > 2 || perm[2] < 0 || perm[2] > 2 ||
+      perm[0] == perm[1] || perm[0] == perm[2] || perm[1] == perm[2])
+    return DPC_E_MODE;
+  if (normalise < 0 || normalise > 2) return DPC_E_MODE;
+  *k = 1.f / (2.f * sigma * sigma);
+  *step = G > 1 ? 2.f / (float)(G - 1) : 0.f;
+  *scale = 1.f;
+  if (normalise == DPC_GAUSS_NORM_ANALYTICAL) {
+    const float sn = sigma * (float)G;                       // point_cloud.py:46-51
+    *scale = 1.f / (1.78984352254f * sn * sn * sn);
+  }
+  return 0;
+}
+
+size_t dpc_gauss_voxelize_workspace_bytes(int B, int G) {
+  if (B <= 0 || G <= 0) return 0;
+  return ((size_t)B * G * G * G + DPC_GV_KC) * sizeof(float);
+}
+
+int dpc_gauss_voxelize_fwd(dpc_stream_t stream, int B, int N, int G, const int* perm, float sigma, int normalise,
+                           const float* pc, float* inv_norm, float* raw, float* vox) {
+  float k, scale, step;
+  int rc = gv_args(B, N, G, perm, sigma, normalise, &k, &scale, &step);
+  if (rc) return rc;
+  if (!pc || !raw || !vox || (normalise == DPC_GAUSS_NORM_SUM && !inv_norm)) return DPC_E_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  const float* inv = nullptr;
+  if (normalise == DPC_GAUSS_NORM_SUM) {
+    const int total = B * N * 3;
+    DPC_LAUNCH("gv_norm", (k_gv_norm), dim3((total + DPC_BLOCK - 1) / DPC_BLOCK, 1, 1), dim3(DPC_BLOCK, 1, 1), 0, st,
+               pc, inv_norm, total, G, k, step);
+    inv = inv_norm;
+  }
+  const int nt = (G + DPC_GV_TILE - 1) / DPC_GV_TILE;
+  DPC_LAUNCH("gv_fwd", (k_gv_fwd), dim3(B, G, nt * nt), dim3(256, 1, 1), 0, st, pc, inv, raw, vox, N, G, perm[0],
+             perm[1], perm[2], k, scale, step);
+  return last_error();
+}
+
+int dpc_gauss_voxelize_bwd(dpc_stream_t stream, int B, int N, int G, const int* perm, float sigma, int normalise,
+                           const float* pc, const float* raw, const float* dvox, float* dpc, void* workspace,
+                           size_t workspace_bytes) {
+  float k, scale, step;
+  int rc = gv_args(B, N, G, perm, sigma, normalise, &k, &scale, &step);
+  if (rc) return rc;
+  if (!pc || !raw || !dvox || !dpc) return DPC_E_NULL;
+  if (!workspace || workspace_bytes < dpc_gauss_voxelize_workspace_bytes(B, G)) return DPC_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* gm = (float*)workspace;
+  const size_t total = (size_t)B * G * G * G;
+  DPC_LAUNCH("gv_mask", (k_gv_mask), dim3((unsigned)((total + DPC_GV_KC + DPC_BLOCK - 1) / DPC_BLOCK), 1, 1),
+             dim3(DPC_BLOCK, 1, 1), 0, st, raw, dvox, gm, total, DPC_GV_KC);
+  DPC_LAUNCH("gv_bwd", (k_gv_bwd), dim3((N + 63) / 64, B, 1), dim3(64, 1, 1), 0, st, pc, (const float*)gm, dpc, N, G,
+             perm[0], perm[1], perm[2], k, scale, step, normalise == DPC_GAUSS_NORM_SUM ? 1 : 0);
   return last_error();
 }
 

@@ -16,7 +16,7 @@ import torch
 
 from . import ops
 from .util.gauss_kernel import smoothing_kernel
-from .util.point_cloud import pc_point_dropout, pointcloud_project_fast
+from .util.point_cloud import pc_point_dropout, pointcloud_project, pointcloud_project_fast
 from .util.quaternion import quaternion_conjugate as q_conj
 from .util.quaternion import quaternion_multiply as q_mul
 from .util.quaternion import quaternion_normalise as q_norm
@@ -145,19 +145,22 @@ class ModelPointCloud(object):
             camera_pose = inputs["matrices"]
         if is_training and cfg.pc_point_dropout != 1:                      # model_pc.py:233-237
             all_points, all_rgb = pc_point_dropout(all_points, all_rgb, self.get_dropout_keep_prob())
-        if not cfg.pc_fast:
-            raise NotImplementedError("slow exact-Gaussian path (pc_fast=false) is SURVEY.md 8(f) scope")
-        predicted_translation = outputs["predicted_translation"] if cfg.predict_translation else None
-        proj_out = pointcloud_project_fast(cfg, all_points, camera_pose, predicted_translation, all_rgb,
-                                           self.gauss_kernel(), scaling_factor=outputs["all_scaling_factors"],
-                                           focal_length=outputs["all_focal_length"])
-        proj = proj_out["proj"]
-        outputs["projs_rgb"] = proj_out["proj_rgb"]
-        # TF1 only computes drc_probs ([Dz+1,B,D,D,1]) if a loss fetches it; here it is
-        # materialised only when such a loss is switched on, and reachable via proj_out otherwise
-        outputs["proj_out"] = proj_out
-        outputs["drc_probs"] = proj_out["drc_probs"] if getattr(cfg, "drc_weight", 0.0) else None
-        outputs["projs_depth"] = proj_out["proj_depth"]
+        if cfg.pc_fast:
+            predicted_translation = outputs["predicted_translation"] if cfg.predict_translation else None
+            proj_out = pointcloud_project_fast(cfg, all_points, camera_pose, predicted_translation, all_rgb,
+                                               self.gauss_kernel(), scaling_factor=outputs["all_scaling_factors"],
+                                               focal_length=outputs["all_focal_length"])
+            proj = proj_out["proj"]
+            outputs["projs_rgb"] = proj_out["proj_rgb"]
+            # TF1 only computes drc_probs ([Dz+1,B,D,D,1]) if a loss fetches it; here it is
+            # materialised only when such a loss is switched on, and reachable via proj_out otherwise
+            outputs["proj_out"] = proj_out
+            outputs["drc_probs"] = proj_out["drc_probs"] if getattr(cfg, "drc_weight", 0.0) else None
+            outputs["projs_depth"] = proj_out["proj_depth"]
+        else:                                                                # model_pc.py:250-253
+            proj, _voxels = pointcloud_project(cfg, all_points, camera_pose, self.gauss_sigma())
+            outputs["projs_rgb"] = None
+            outputs["projs_depth"] = None
         outputs["projs"] = proj
         batch_size = outputs["points_1"].shape[0]
         outputs["projs_1"] = proj[0:batch_size]

@@ -27,6 +27,7 @@ class Config(dict):
         pc_rgb_divide_by_occupancies=False,
         pc_rgb_divide_by_occupancies_epsilon=0.01,
         # caller side (dpc/models/model_pc.py:225-299)
+        pc_normalise_gauss=False, pc_normalise_gauss_analytical=True,     # :51-52 (slow path only)
         pc_fast=True, predict_pose=False, predict_translation=False,
         pc_point_dropout=1.0, pc_learn_occupancy_scaling=True,
         pose_predict_num_candidates=1, step_size=4, batch_size=8,

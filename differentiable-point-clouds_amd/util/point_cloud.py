@@ -109,12 +109,31 @@ def convolve_rgb(cfg, voxels_rgb, kernel):
     return _convolve_cm(cfg, cm, kernel).permute(0, 2, 3, 4, 1)
 
 
+def _gauss_norm_mode(cfg):
+    if getattr(cfg, "pc_normalise_gauss", False):                      # point_cloud.py:43-45
+        return 1
+    if getattr(cfg, "pc_normalise_gauss_analytical", False):           # point_cloud.py:46-51
+        return 2
+    return 0
+
+
 def pointcloud2voxels(cfg, input_pc, sigma):
-    raise NotImplementedError("exact O(N D^3) Gaussian voxeliser (pc_fast=false) is SURVEY.md 8(f) scope")
+    """dpc/util/point_cloud.py:17-57: exact Gaussian splat of [B,N,3] points onto the
+    vox_size^3 lattice over [-1,1]^3 -> [B,G,G,G,1] in the reference's meshgrid layout
+    (axis 1 <- component 1, axis 2 <- component 0, axis 3 <- component 2)."""
+    vox = ops.GaussVoxelize.apply(input_pc, float(sigma), int(cfg.vox_size), (1, 0, 2), _gauss_norm_mode(cfg))
+    return vox.unsqueeze(-1)
 
 
 def pointcloud_project(cfg, point_cloud, transform, sigma):
-    raise NotImplementedError("slow path (pc_fast=false) is SURVEY.md 8(f) scope")
+    """dpc/util/point_cloud.py:219-226 (cfg.pc_fast:false): perspective transform ->
+    exact Gaussian voxels -> transpose [0,2,1,3,4] -> DRC -> H flip.  Returns
+    (proj [B,G,G,1], voxels [B,G,G,G,1]); the transposed layout is produced directly."""
+    tr_pc = pc_perspective_transform(cfg, point_cloud, transform)
+    vox = ops.GaussVoxelize.apply(tr_pc, float(sigma), int(cfg.vox_size), (0, 1, 2), _gauss_norm_mode(cfg))
+    voxels = vox.unsqueeze(-1)
+    _, proj = _drc.drc_event_probabilities_impl(voxels, cfg, flip_h=True)       # tf.reverse(proj, [1])
+    return proj, voxels
 
 
 class ProjectionOutputs(dict):

@@ -207,6 +207,28 @@ int dpc_silhouette_loss_bwd(dpc_stream_t stream, int B, int C, int D, int S, con
 int dpc_nn_distance(dpc_stream_t stream, int dtype_bytes, int ns, int nt, const void* vs,
                     const void* vt, void* proj, void* min_dist, int32_t* idx);
 
+/* Exact Gaussian voxeliser: replaces pointcloud2voxels
+ * (dpc/util/point_cloud.py:17-57), the cfg.pc_fast:false splat of
+ * pointcloud_project (:219-226).  pc [B,N,3]; lattice of G nodes per axis
+ * spanning [-1,1]; output axis a takes point component perm[a]
+ * (pointcloud2voxels' own meshgrid layout is perm = {1,0,2}; the layout after
+ * pointcloud_project's transpose, [b,iz,iy,ix] for tr_pc = (w,v,u), is
+ * {0,1,2}).  normalise: DPC_GAUSS_NORM_NONE, _SUM (cfg.pc_normalise_gauss:
+ * every point's Gaussian divided by its sum over the lattice; needs inv_norm
+ * [B,N,3] scratch) or _ANALYTICAL (cfg.pc_normalise_gauss_analytical, the
+ * default).  raw [B,G,G,G] = summed Gaussians (saved for backward), vox =
+ * clip(raw,0,1).  Backward: dpc [B,N,3] from dvox; workspace of
+ * dpc_gauss_voxelize_workspace_bytes(B,G) bytes. */
+#define DPC_GAUSS_NORM_NONE 0
+#define DPC_GAUSS_NORM_SUM 1
+#define DPC_GAUSS_NORM_ANALYTICAL 2
+size_t dpc_gauss_voxelize_workspace_bytes(int B, int G);
+int dpc_gauss_voxelize_fwd(dpc_stream_t stream, int B, int N, int G, const int* perm, float sigma,
+                           int normalise, const float* pc, float* inv_norm, float* raw, float* vox);
+int dpc_gauss_voxelize_bwd(dpc_stream_t stream, int B, int N, int G, const int* perm, float sigma,
+                           int normalise, const float* pc, const float* raw, const float* dvox,
+                           float* dpc, void* workspace, size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -204,3 +204,59 @@ def nn_distance_gradient(dev):
     ((sel - vs).pow(2).sum(1).sqrt().sum() + (w * sel).sum()).backward()
     assert maxabs(g_vs.cpu().numpy(), vs.grad.cpu().numpy()) < 1e-12
     assert maxabs(g_vt.cpu().numpy(), vt.grad.cpu().numpy()) < 1e-12
+
+
+SLOW_VOX_CASES = ["vox_analytical", "vox_none", "vox_sum"]
+
+
+def _slow_cfg(G, nsum=False, nana=True):
+    return dpc_amd.default_config(vox_size=G, pc_normalise_gauss=bool(nsum), pc_normalise_gauss_analytical=bool(nana),
+                                  pc_fast=False)
+
+
+def gauss_voxeliser_matches_reference(dev, name):
+    """pointcloud2voxels (point_cloud.py:17-57) against goldens from the reference's own source:
+    the three normalisation modes, clipped pile-ups, gradient of a random functional."""
+    from dpc_amd.util.point_cloud import pointcloud2voxels
+    from helpers import load
+    g = load("slow_path")
+    B, N, G, nsum, nana = (int(v) for v in g[name + "_meta"])
+    pc = torch.tensor(g[name + "_pc"], device=dev, requires_grad=True)
+    vox = pointcloud2voxels(_slow_cfg(G, nsum, nana), pc, float(g[name + "_sigma"]))
+    assert vox.shape == (B, G, G, G, 1)
+    assert maxabs(vox.detach().cpu().numpy(), g[name + "_vox_f64"]) < 1e-5
+    (vox * torch.tensor(g[name + "_w"], device=dev)).sum().backward()
+    assert relerr(pc.grad.cpu().numpy(), g[name + "_dpc_f64"]) < TOL_GRAD
+
+
+def slow_projector_matches_reference(dev):
+    """pointcloud_project (point_cloud.py:219-226, cfg.pc_fast:false) end to end."""
+    from dpc_amd.util.point_cloud import pointcloud_project
+    from helpers import load
+    g = load("slow_path")
+    B, N, G = (int(v) for v in g["proj_meta"])
+    pc = torch.tensor(g["proj_pc"], device=dev, requires_grad=True)
+    pose = torch.tensor(g["proj_pose"], device=dev, requires_grad=True)
+    proj, vox = pointcloud_project(_slow_cfg(G), pc, pose, float(g["proj_sigma"]))
+    assert proj.shape == (B, G, G, 1) and vox.shape == (B, G, G, G, 1)
+    assert maxabs(vox.detach().cpu().numpy(), g["proj_vox_f64"]) < 1e-5
+    assert maxabs(proj.detach().cpu().numpy(), g["proj_proj_f64"]) < TOL_PROJ
+    (proj * torch.tensor(g["proj_w"], device=dev)).sum().backward()
+    assert relerr(pc.grad.cpu().numpy(), g["proj_dpc_f64"]) < TOL_GRAD
+    assert relerr(pose.grad.cpu().numpy(), g["proj_dpose_f64"]) < TOL_GRAD
+
+
+def gauss_voxeliser_multitile_against_numpy_oracle(dev, B=1, N=100, G=70, sigma=0.05, mode="analytical"):
+    """lattice wider than one 64-node tile, N not a multiple of the point chunk: against the
+    NumPy fp64 restatement (itself pinned to the reference goldens in test_oracle.py)."""
+    gen = np.random.default_rng(12)
+    pc = gen.uniform(-0.95, 0.95, (B, N, 3)).astype(np.float32)
+    w = gen.standard_normal((B, G, G, G)).astype(np.float32)
+    ref, raw = onp.gauss_voxelize_fwd(pc, G, sigma, mode)
+    dref = onp.gauss_voxelize_bwd(pc, G, sigma, raw, w.astype(np.float64), mode)
+    t = torch.tensor(pc, device=dev, requires_grad=True)
+    nmode = {None: 0, "sum": 1, "analytical": 2}[mode]
+    vox = dpc_amd.ops.GaussVoxelize.apply(t, sigma, G, (1, 0, 2), nmode)
+    assert maxabs(vox.detach().cpu().numpy(), ref) < 1e-5 * max(1.0, float(ref.max()))
+    (vox * torch.tensor(w, device=dev)).sum().backward()
+    assert relerr(t.grad.cpu().numpy(), dref) < TOL_GRAD

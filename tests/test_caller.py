@@ -126,3 +126,21 @@ def test_student_loss_matches_reference(emu):
     assert abs(float(loss) - float(g["student_loss_f64"])) < 1e-4 * float(g["student_loss_f64"])
     assert relerr(stud.grad.numpy(), g["student_dstudent_f64"]) < 1e-4
     assert relerr(poses.grad.numpy(), g["student_dposes_f64"]) < 2e-4
+
+
+def test_compute_projection_slow_path(emu):
+    """cfg.pc_fast:false branch of compute_projection (model_pc.py:250-253): exact Gaussian
+    splat, no depth / RGB outputs; the loss still back-propagates to points and poses."""
+    g = load("caller_toy")
+    cfg = _cfg(g)
+    cfg.pc_fast = False
+    model = M.ModelPointCloud(cfg, global_step=int(g["global_step"]), device="cpu")
+    pts = torch.tensor(g["points_1"], requires_grad=True)
+    poses = torch.tensor(g["poses"], requires_grad=True)
+    outputs = model.replicate_outputs({"points_1": pts, "poses": poses, "scaling_factor": torch.tensor(g["scaling_factor"]),
+                                       "focal_length": None})
+    inputs = {"masks": torch.tensor(g["masks"])}
+    outputs = model.compute_projection(inputs, outputs, is_training=False)
+    assert outputs["projs"].shape == (8, 16, 16, 1) and outputs["projs_depth"] is None and outputs["projs_rgb"] is None
+    model.add_proj_loss(inputs, outputs, 1.0).backward()
+    assert torch.isfinite(pts.grad).all() and float(pts.grad.abs().sum()) > 0 and float(poses.grad.abs().sum()) > 0

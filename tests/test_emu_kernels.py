@@ -88,3 +88,16 @@ def test_emu_nn_distance(emu, name, tag):
 def test_emu_nn_distance_gradient(emu):
     parity_cases.nn_distance_gradient("cpu")
 
+
+@pytest.mark.parametrize("name", parity_cases.SLOW_VOX_CASES)
+def test_emu_gauss_voxeliser(emu, name):
+    parity_cases.gauss_voxeliser_matches_reference("cpu", name)
+
+
+def test_emu_slow_projector(emu):
+    parity_cases.slow_projector_matches_reference("cpu")
+
+
+def test_emu_gauss_voxeliser_multitile(emu):
+    parity_cases.gauss_voxeliser_multitile_against_numpy_oracle("cpu", N=70, G=66)
+

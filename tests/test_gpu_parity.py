@@ -169,6 +169,20 @@ def test_nn_distance_gradient_and_brute_force_at_scale():
     assert torch.equal(proj, vt[idx.to(torch.int64)])
 
 
+@pytest.mark.parametrize("name", parity_cases.SLOW_VOX_CASES)
+def test_gauss_voxeliser(name):
+    parity_cases.gauss_voxeliser_matches_reference("cuda", name)
+
+
+def test_slow_projector():
+    parity_cases.slow_projector_matches_reference("cuda")
+
+
+@pytest.mark.parametrize("mode", [None, "sum", "analytical"])
+def test_gauss_voxeliser_multitile(mode):
+    parity_cases.gauss_voxeliser_multitile_against_numpy_oracle("cuda", B=2, N=333, G=70, sigma=0.06, mode=mode)
+
+
 def test_d256_fused_path_against_numpy_oracle():
     """256^3 grid (BASELINE configs[4] resolution) at B=1: k_splat_xy / k_gather_yx with 32-row
     strips and 16-byte lanes, against the float64 NumPy oracle."""
