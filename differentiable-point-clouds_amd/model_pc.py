@@ -15,7 +15,9 @@ import math
 import torch
 
 from . import ops
-from .util.gauss_kernel import smoothing_kernel
+from .util.gauss_kernel import gauss_smoothen_image, smoothing_kernel
+from .util.losses import (add_drc_loss, add_proj_depth_loss, add_proj_rgb_loss,  # noqa: F401
+                          resize_images_bilinear_tf1)
 from .util.point_cloud import pc_point_dropout, pointcloud_project, pointcloud_project_fast
 from .util.quaternion import quaternion_conjugate as q_conj
 from .util.quaternion import quaternion_multiply as q_mul
@@ -47,28 +49,6 @@ def get_dropout_prob(cfg, global_step):
         k = (keep_end - keep_start) / (end_step - start_step)
         keep = k * x + (keep_start - k * start_step)
     return float(min(max(keep, keep_start), keep_end))
-
-
-def resize_images_bilinear_tf1(images, size):
-    """tf.image.resize_images(..., BILINEAR), TF1 legacy sampling
-    (align_corners=False, no half-pixel centres): src = dst * in/out.
-    images [B,H,W,C] -> [B,size,size,C] (model_pc.py:392-397)."""
-    n, ih, iw, c = images.shape
-    oh, ow = int(size[0]), int(size[1])
-
-    def axis(o, i):
-        src = torch.arange(o, dtype=torch.float64, device=images.device) * (i / o)
-        lo = torch.floor(src).to(torch.int64)
-        hi = torch.clamp(lo + 1, max=i - 1)
-        return lo, hi, (src - lo.to(torch.float64)).to(images.dtype)
-    ylo, yhi, yl = axis(oh, ih)
-    xlo, xhi, xl = axis(ow, iw)
-    xl = xl.view(1, 1, -1, 1)
-    yl = yl.view(1, -1, 1, 1)
-    rows_lo, rows_hi = images[:, ylo], images[:, yhi]
-    top = rows_lo[:, :, xlo] * (1 - xl) + rows_lo[:, :, xhi] * xl
-    bot = rows_hi[:, :, xlo] * (1 - xl) + rows_hi[:, :, xhi] * xl
-    return top * (1 - yl) + bot * yl
 
 
 class ModelPointCloud(object):
@@ -200,10 +180,14 @@ class ModelPointCloud(object):
         assert gt_size >= pred_size, "GT size should not be higher than prediction size"
         if gt_size > pred_size and cfg.bicubic_gt_downsampling:
             raise NotImplementedError("bicubic GT downsampling")
-        if cfg.pc_gauss_filter_gt:
-            raise NotImplementedError("Gaussian-filtered GT (off by default, default_config.yaml:93)")
+        if cfg.pc_gauss_filter_gt:                                          # model_pc.py:398-404
+            if gt_size > pred_size:
+                gt = resize_images_bilinear_tf1(gt, [pred_size, pred_size])
+            smoothed = gauss_smoothen_image(cfg, gt, self._sigma_rel)
+            if not (cfg.pc_gauss_filter_gt_switch_off and self._sigma_rel < 1.0):
+                gt = smoothed
         total_loss = 0
-        # the bilinear GT resize (model_pc.py:392-397) happens inside the loss kernel
+        # otherwise the bilinear GT resize (model_pc.py:392-397) happens inside the loss kernel
         if cfg.pose_predict_num_candidates > 1:
             proj_loss, min_loss = self.proj_loss_pose_candidates(gt, pred, inputs)
             outputs["winning_pose_candidates"] = min_loss
@@ -213,3 +197,20 @@ class ModelPointCloud(object):
             proj_loss, _, _ = ops.SilhouetteLoss.apply(pred, gt, None, 1)
         total_loss = total_loss + proj_loss
         return total_loss * weight_scale
+
+    def get_loss(self, inputs, outputs, add_summary=True):                     # model_pc.py:425-445
+        cfg = self.cfg()
+        g_loss = 0
+        if cfg.proj_weight:
+            g_loss = g_loss + self.add_proj_loss(inputs, outputs, cfg.proj_weight, add_summary)
+        if cfg.drc_weight:
+            if outputs.get("drc_probs") is None:
+                outputs["drc_probs"] = outputs["proj_out"]["drc_probs"]
+            g_loss = g_loss + add_drc_loss(cfg, inputs, outputs, cfg.drc_weight, add_summary)
+        if cfg.pc_rgb:
+            g_loss = g_loss + add_proj_rgb_loss(cfg, inputs, outputs, cfg.proj_rgb_weight, add_summary, self._sigma_rel)
+        if cfg.proj_depth_weight:
+            g_loss = g_loss + add_proj_depth_loss(cfg, inputs, outputs, cfg.proj_depth_weight, self._sigma_rel,
+                                                  add_summary)
+        return g_loss
+

@@ -37,7 +37,8 @@ class Config(dict):
         pose_predictor_student=True, pose_predictor_student_loss_weight=1.0,
         pose_student_align_loss=False, variable_num_views=False,
         # loss side (model_pc.py:383-445)
-        bicubic_gt_downsampling=False, pc_gauss_filter_gt=False,
+        bicubic_gt_downsampling=False, pc_gauss_filter_gt=False, pc_gauss_filter_gt_rgb=False,
+        pc_gauss_filter_gt_switch_off=False, proj_rgb_weight=0.0, max_dataset_depth=10.0,
         proj_weight=1.0, drc_weight=0.0, proj_depth_weight=0.0,
     )
 

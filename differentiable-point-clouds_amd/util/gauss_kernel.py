@@ -28,6 +28,18 @@ def gauss_kernel_1d(l, sig, device=None):
     return kernel / kernel.sum()
 
 
+def gauss_smoothen_image(cfg, img, sigma_rel):
+    """dpc/util/gauss_kernel.py:14-24: per-channel separable blur of [B,H,W,C] images, SAME zero
+    padding (GT masks / images only; a few launches of stock depthwise conv on small tensors)."""
+    fsz = int(cfg.pc_gauss_kernel_size)
+    kernel = gauss_kernel_1d(fsz, sigma_rel, img.device).to(img.dtype)
+    c = img.shape[-1]
+    x = img.permute(0, 3, 1, 2)
+    x = torch.nn.functional.conv2d(x, kernel.reshape(1, 1, 1, fsz).repeat(c, 1, 1, 1), padding=(0, fsz // 2), groups=c)
+    x = torch.nn.functional.conv2d(x, kernel.reshape(1, 1, fsz, 1).repeat(c, 1, 1, 1), padding=(fsz // 2, 0), groups=c)
+    return x.permute(0, 2, 3, 1)
+
+
 def separable_kernels(kernel):
     size = kernel.shape[0]
     return [kernel.reshape(1, 1, size, 1, 1), kernel.reshape(1, size, 1, 1, 1),

@@ -415,6 +415,14 @@ def reduce_mean(x, axis=None, keepdims=False):
     return _wrap(_torch.mean(x) if axis is None else _torch.mean(x, dim=_axes(axis), keepdim=keepdims))
 
 
+def equal(a, b):
+    return _wrap(_t(a) == b)
+
+
+def not_equal(a, b):
+    return _wrap(_t(a) != b)
+
+
 def less(a, b):
     return _wrap(_t(a) < _t(b))
 

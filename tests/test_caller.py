@@ -144,3 +144,38 @@ def test_compute_projection_slow_path(emu):
     assert outputs["projs"].shape == (8, 16, 16, 1) and outputs["projs_depth"] is None and outputs["projs_rgb"] is None
     model.add_proj_loss(inputs, outputs, 1.0).backward()
     assert torch.isfinite(pts.grad).all() and float(pts.grad.abs().sum()) > 0 and float(poses.grad.abs().sum()) > 0
+
+
+def _run_losses(dev, name):
+    """get_loss (model_pc.py:425-445): silhouette + DRC + RGB + depth terms on the toy RGB case."""
+    g = load("caller_losses_rgb")
+    extra = dict(pc_gauss_filter_gt=True, pc_gauss_filter_gt_rgb=True) if name == "filtered" else {}
+    cfg = dpc_amd.default_config(vox_size=int(g["D"]), pc_gauss_kernel_size=int(g["K"]), pc_relative_sigma=3.0,
+                                 pc_relative_sigma_end=0.2, predict_pose=True, pose_predict_num_candidates=1,
+                                 step_size=int(g["V"]), batch_size=int(g["Bm"]), pose_predictor_student=False,
+                                 pc_rgb=True, drc_weight=0.3, proj_rgb_weight=0.7, proj_depth_weight=0.2,
+                                 max_depth=12.0, max_dataset_depth=10.0, **extra)
+    model = M.ModelPointCloud(cfg, global_step=int(g["global_step"]), device=dev)
+    leaves = {k: torch.tensor(g[k], device=dev, requires_grad=True) for k in ("points_1", "rgb_1", "poses", "scaling_factor")}
+    outputs = model.replicate_outputs({"points_1": leaves["points_1"], "rgb_1": leaves["rgb_1"], "poses": leaves["poses"],
+                                       "scaling_factor": leaves["scaling_factor"], "focal_length": None})
+    inputs = {k: torch.tensor(g[k], device=dev) for k in ("masks", "images", "depths")}
+    outputs = model.compute_projection(inputs, outputs, is_training=False)
+    loss = model.get_loss(inputs, outputs)
+    loss.backward()
+    ref = float(g[name + "_loss_f64"])
+    assert abs(float(loss) - ref) < 2e-5 * ref, (float(loss), ref)
+    for k, v in leaves.items():
+        assert relerr(v.grad.cpu().numpy(), g["%s_d%s_f64" % (name, k)]) < 2e-4, k
+
+
+@pytest.mark.parametrize("name", ["plain", "filtered"])
+def test_get_loss_all_terms_emulated(emu, name):
+    _run_losses("cpu", name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["plain", "filtered"])
+def test_get_loss_all_terms_gpu(name):
+    dpc_amd._capi.set_library(None)
+    _run_losses("cuda", name)
