@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="views per GPU (default: the config's)")
     ap.add_argument("--points", default="shell", choices=["shell", "ball"],
                     help="synthetic cloud: noisy sphere shell (surface-like, default) or uniform ball (SURVEY.md 8(d))")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one fwd+bwd step in a HIP graph and replay it (launch-bound small configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -155,12 +157,26 @@ def main():
     lib = dpc_amd.get_library()
     case = build_case(args.config, args.batch, device, seed_offset=1000 * rank, kind=args.points)
 
+    run = lambda: step(case)
+    if args.graph:
+        # the library only enqueues on the stream it is handed, so a whole step (forward, loss
+        # gradient, backward) records into one hipGraph; replay costs one launch on the host
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step(case)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            case["graph_grads"] = step(case)
+        run = graph.replay
     for _ in range(args.warmup):
-        step(case)
+        run()
     dd.barrier(device)                      # barrier + torch.cuda.synchronize() on both sides
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(case)
+        run()
     dd.barrier(device)
     elapsed = dd.max_over_ranks(time.perf_counter() - t0, device)
 
@@ -214,7 +230,7 @@ def main():
                                    "grid %d^3, K=%d, sigma=%.1f, batch %d views per GPU, %s point clouds, "
                                    "dproj=(proj-gt)/B" % ({1: 0, 2: 1, 5: 4}[args.config], case["N"], case["D"],
                                                          case["K"], case["sigma"], case["B"], args.points),
-                       "global_batch": world * case["B"], "K": case["K"], "parallelism": "views sharded x%d, "
+                       "global_batch": world * case["B"], "K": case["K"], "hip_graph": bool(args.graph), "parallelism": "views sharded x%d, "
                        "no data-path collective" % world},
             "roofline": roof,
         }
