@@ -107,10 +107,14 @@ def _taps_of(taps):
     return tuple(ts), tuple(ks)
 
 
+_POISON = bool(os.environ.get("DPC_POISON_BUFFERS"))        # read once: this sits on the per-step host path
+
+
 def _poison(t):
-    """DPC_POISON_BUFFERS=1 (set by the test-suite): NaN-fill every buffer the kernels are supposed
-    to fully define or deliberately skip, so that a read of a never-written element cannot hide."""
-    if t is not None and os.environ.get("DPC_POISON_BUFFERS") and t.is_floating_point():
+    """DPC_POISON_BUFFERS=1 (set by the test-suite before import): NaN-fill every buffer the kernels
+    are supposed to fully define or deliberately skip, so that a read of a never-written element
+    cannot hide."""
+    if _POISON and t is not None and t.is_floating_point():
         t.fill_(float("nan"))
     return t
 

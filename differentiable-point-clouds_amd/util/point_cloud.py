@@ -48,6 +48,23 @@ def _flat_taps(cfg, kernel, device):
         return None, None, None
     if not cfg.pc_separable_gauss_filter or isinstance(kernel, torch.Tensor):
         raise NotImplementedError("dense 3-D Gaussian kernel (pc_separable_gauss_filter=false)")
+    # the filters only change when sigma does (every step at most, usually far less often), the
+    # projector runs every step: remember the flattened taps of the last filter list seen
+    if not all(isinstance(k, torch.Tensor) for k in kernel):
+        return _flat_taps_uncached(kernel, device)
+    key = tuple((id(k), k._version) for k in kernel) + (str(device),)      # _version: in-place edits invalidate
+    hit = _TAPS_CACHE.get("key")
+    if hit == key and all(a is b for a, b in zip(_TAPS_CACHE["filters"], kernel)):
+        return _TAPS_CACHE["taps"]
+    out = _flat_taps_uncached(kernel, device)
+    _TAPS_CACHE.update(key=key, filters=list(kernel), taps=out)
+    return out
+
+
+_TAPS_CACHE = {}
+
+
+def _flat_taps_uncached(kernel, device):
     taps = {"x": None, "y": None, "z": None}
     for k in kernel:
         if not (isinstance(k, torch.Tensor) and k.dtype == torch.float32):
