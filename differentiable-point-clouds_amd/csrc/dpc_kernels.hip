@@ -940,6 +940,33 @@ k_blur_xy_stream(const float* __restrict__ in, float* __restrict__ out, const fl
 // per touched corner (cmask [B,N,4] bytes: byte k*2+j, bit l).
 // ===========================================================================
 
+// In-place exclusive prefix sum of h[0..M) over the work-group, total into h[M] (M <= a few hundred:
+// the per-view depth-cell histogram).  Every thread of the block must call it; ends with a barrier.
+__device__ __forceinline__ void block_exclusive_scan(int* h, int M) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int per = (M + nth - 1) / nth;
+  const int lo = tid * per < M ? tid * per : M, hi = lo + per < M ? lo + per : M;
+  int own = 0;
+  for (int i = lo; i < hi; ++i) own += h[i];
+  part[tid] = own;
+  __syncthreads();
+  for (int off = 1; off * per < M && off < nth; off <<= 1) {   // threads beyond the last owner hold 0
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - own;
+  for (int i = lo; i < hi; ++i) {
+    const int c = h[i];
+    h[i] = run;
+    run += c;
+  }
+  if (hi == M && lo < M) h[M] = run;   // the owner of the last entry also knows the total
+  __syncthreads();
+}
+
 // camera transform of one view's points (-> tr_pc) followed by an LDS counting
 // sort by depth cell iz (bin Dz = dropped points)
 template <bool QUAT>
@@ -987,16 +1014,7 @@ k_zsort(DpcShape S, DpcParams P, const float* __restrict__ pc, const float* __re
       }
     }
     __syncthreads();
-    if (tid == 0) {
-      int run = 0;
-      for (int i = 0; i <= Dz; ++i) {
-        const int cnt = hist[i];
-        hist[i] = run;
-        run += cnt;
-      }
-      hist[Dz + 1] = run;
-    }
-    __syncthreads();
+    block_exclusive_scan(hist, Dz + 1);
     for (int i = tid; i < Dz + 2; i += nth) zstart[(size_t)b * (Dz + 2) + i] = hist[i];
     __syncthreads();
 #pragma unroll
@@ -1019,16 +1037,7 @@ k_zsort(DpcShape S, DpcParams P, const float* __restrict__ pc, const float* __re
     atomicAdd(&hist[c.valid ? c.iz : Dz], 1);
   }
   __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int i = 0; i <= Dz; ++i) {
-      const int cnt = hist[i];
-      hist[i] = run;
-      run += cnt;
-    }
-    hist[Dz + 1] = run;
-  }
-  __syncthreads();
+  block_exclusive_scan(hist, Dz + 1);
   for (int i = tid; i < Dz + 2; i += nth) zstart[(size_t)b * (Dz + 2) + i] = hist[i];
   __syncthreads();
   for (int n = tid; n < N; n += nth) {  // tr_pc rows written above by this same work-group
