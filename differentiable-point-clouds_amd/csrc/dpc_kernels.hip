@@ -2189,20 +2189,22 @@ __global__ void __launch_bounds__(DPC_BLOCK) k_sil_grad(const float* __restrict_
 // Nearest-neighbour distance (reference util/point_cloud_distance.py:26-39, the Chamfer
 // evaluation of run/eval_chamfer.py:18-34): for every source point the closest target
 // point, in the tensor's own precision (fp64 in the evaluation).  Brute force, targets
-// streamed through LDS; a work-group is 64 sources x 4 target phases (wave w takes every
-// 4th target), merged lexicographically on (distance, index) so the result is tf.argmin's
-// first minimum of sqrt(sum diff^2) exactly.
+// streamed through LDS; a work-group is 256/PH sources x PH target phases (phase p takes every
+// PH-th target), merged lexicographically on (distance, index) so the result is tf.argmin's
+// first minimum of sqrt(sum diff^2) exactly.  PH = 16 for small source sets (an evaluation has
+// ~8000 predicted points: 64 sources per work-group would leave half the chip idle).
 // ===========================================================================
 #define DPC_NN_CHUNK 1024
-template <typename T>
+template <typename T, int PH>
 __global__ void __launch_bounds__(256) k_nn_distance(const T* __restrict__ vs, const T* __restrict__ vt, int ns, int nt,
                                                      T* __restrict__ proj, T* __restrict__ min_dist,
                                                      int* __restrict__ idx) {
   __shared__ T tile[DPC_NN_CHUNK * 3];
   __shared__ T m_s[256];
   __shared__ int m_i[256];
-  const int tid = threadIdx.x, lane = tid & 63, phase = tid >> 6;
-  const int s = blockIdx.x * 64 + lane;
+  constexpr int SRC = 256 / PH;
+  const int tid = threadIdx.x, lane = tid % SRC, phase = tid / SRC;
+  const int s = blockIdx.x * SRC + lane;
   const int sc = s < ns ? s : ns - 1;
   const T sx = vs[(size_t)sc * 3], sy = vs[(size_t)sc * 3 + 1], sz = vs[(size_t)sc * 3 + 2];
   T best_d2 = (T)INFINITY, best_s = (T)INFINITY;
@@ -2212,7 +2214,7 @@ __global__ void __launch_bounds__(256) k_nn_distance(const T* __restrict__ vs, c
     __syncthreads();
     for (int i = tid; i < cnt * 3; i += 256) tile[i] = vt[(size_t)base * 3 + i];
     __syncthreads();
-    for (int j = phase; j < cnt; j += 4) {
+    for (int j = phase; j < cnt; j += PH) {
 #pragma clang fp contract(off)
       // (vt - vs)^2 summed x, y, z in this order without FMA contraction, as tf.reduce_sum(diff**2, axis=2) does
       const T dx = tile[j * 3] - sx, dy = tile[j * 3 + 1] - sy, dz = tile[j * 3 + 2] - sz;
@@ -2231,9 +2233,9 @@ __global__ void __launch_bounds__(256) k_nn_distance(const T* __restrict__ vs, c
   m_i[tid] = best_i;
   __syncthreads();
   if (phase == 0 && s < ns) {
-    for (int w = 1; w < 4; ++w) {
-      const T os = m_s[w * 64 + lane];
-      const int oi = m_i[w * 64 + lane];
+    for (int w = 1; w < PH; ++w) {
+      const T os = m_s[w * SRC + lane];
+      const int oi = m_i[w * SRC + lane];
       if (os < best_s || (os == best_s && oi < best_i)) {
         best_s = os;
         best_i = oi;
@@ -2814,14 +2816,20 @@ int dpc_nn_distance(dpc_stream_t stream, int dtype_bytes, int ns, int nt, const 
   if (ns <= 0 || nt <= 0) return DPC_E_SHAPE;
   if (dtype_bytes != 4 && dtype_bytes != 8) return DPC_E_MODE;
   if (!vs || !vt || !proj || !min_dist || !idx) return DPC_E_NULL;
-  const dim3 grid((ns + 63) / 64, 1, 1), block(256, 1, 1);
+  const dim3 block(256, 1, 1);
+  const bool wide = ns > 32768;   // enough sources to fill the chip with 64 per work-group
+  const dim3 grid(wide ? (ns + 63) / 64 : (ns + 15) / 16, 1, 1);
+#define DPC_NN(T, PH, label)                                                                                   \
+  DPC_LAUNCH(label, (k_nn_distance<T, PH>), grid, block, 0, (hipStream_t)stream, (const T*)vs, (const T*)vt, ns, nt, \
+             (T*)proj, (T*)min_dist, (int*)idx)
   if (dtype_bytes == 8) {
-    DPC_LAUNCH("nn_distance_f64", (k_nn_distance<double>), grid, block, 0, (hipStream_t)stream, (const double*)vs,
-               (const double*)vt, ns, nt, (double*)proj, (double*)min_dist, (int*)idx);
+    if (wide) DPC_NN(double, 4, "nn_distance_f64");
+    else DPC_NN(double, 16, "nn_distance_f64");
   } else {
-    DPC_LAUNCH("nn_distance_f32", (k_nn_distance<float>), grid, block, 0, (hipStream_t)stream, (const float*)vs,
-               (const float*)vt, ns, nt, (float*)proj, (float*)min_dist, (int*)idx);
+    if (wide) DPC_NN(float, 4, "nn_distance_f32");
+    else DPC_NN(float, 16, "nn_distance_f32");
   }
+#undef DPC_NN
   return last_error();
 }
 

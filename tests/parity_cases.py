@@ -89,6 +89,44 @@ FUSED_CASES = [
 ]
 
 
+FUSED_CASES_GPU = FUSED_CASES + [
+    (1, 9000, 64, 64, 11, 1.6, False, False),    # more than 8 x 1024 points: k_zsort's strided (unbatched) branch
+    (9, 200, 128, 128, 5, 1.0, True, True),      # B = 9 (odd XCD split), K = 5 at 128^3
+    (1, 2000, 128, 128, 21, 3.0, False, False),  # K = 21 at 128^3
+    (2, 300, 32, 32, 11, 1.2, False, False),     # smallest fused lattice
+    (1, 1500, 128, 64, 11, 1.6, False, False),   # vox_size_z = vox_size / 2 at 128: Kz = 5
+]
+
+
+def _nudge_off_cell_faces(inp, trans, focal, Dz, D, tol=3e-5):
+    """Gradient checks against the fp64 oracle need inputs away from the two places where the
+    function is only piecewise smooth and fp32 rounding can pick the other piece:
+      * the trilinear gradient jumps across cell faces (lattice coordinate within rounding of an
+        integer), and
+      * clip_by_value(G0, 0, 1) switches the gradient off where piled-up points sum to 1 +- rounding.
+    Points involved in either coincidence are moved a little (0.3 %), until none is left."""
+    f64 = lambda a: None if a is None else a.astype(np.float64)
+    pc = inp["pc"].copy()
+    size = np.array([Dz - 1, D - 1, D - 1], dtype=np.float64)
+    for _ in range(12):
+        tr = onp.transform_fwd(f64(pc), f64(inp["pose"]), f64(trans), f64(focal))
+        g = (tr + 0.5) * size
+        bad = (np.abs(g - np.rint(g)) < tol).any(-1)
+        G0 = onp.voxelize_fwd(tr, Dz, D)
+        knife = np.abs(G0 - 1.0) < tol
+        if knife.any():
+            lo = np.floor(g).astype(np.int64)
+            inside = ((tr >= -0.5) & (tr <= 0.5)).all(-1)
+            for b, z, y, x in zip(*np.nonzero(knife)):
+                d = np.array([z, y, x]) - lo[b]
+                bad[b] |= inside[b] & ((d >= 0) & (d <= 1)).all(-1)
+        if not bad.any():
+            break
+        pc[bad] *= np.float32(1.003)
+    inp["pc"] = pc
+    return inp
+
+
 def fused_path_against_numpy_oracle(dev, B, N, D, Dz, K, sigma, with_trans, with_focal):
     """pointcloud_project_fast on shapes that use k_zsort/k_splat_xy/k_gather_yx,
     forward and all gradients (incl. depth upstream) vs the float64 NumPy oracle."""
@@ -96,6 +134,7 @@ def fused_path_against_numpy_oracle(dev, B, N, D, Dz, K, sigma, with_trans, with
     inp = synth.make_inputs(B, N, 900 + N)
     trans = (0.04 * rng.standard_normal((B, 3))).astype(np.float32) if with_trans else None
     focal = rng.uniform(1.7, 2.1, (B, 1)).astype(np.float32) if with_focal else None
+    inp = _nudge_off_cell_faces(inp, trans, focal, Dz, D)
     cfg = dpc_amd.default_config(vox_size=D, vox_size_z=(Dz if Dz != D else -1), pc_gauss_kernel_size=K)
     lib = dpc_amd.get_library()
     Kz = len(onp.smoothing_taps(D, Dz if Dz != D else -1, K, sigma)[2])

@@ -136,7 +136,7 @@ def test_odd_sizes_and_generic_tap_counts(D, K):
     parity_cases.odd_sizes_and_generic_tap_counts("cuda", D, K)
 
 
-@pytest.mark.parametrize("case", parity_cases.FUSED_CASES)
+@pytest.mark.parametrize("case", parity_cases.FUSED_CASES_GPU)
 def test_fused_path_against_numpy_oracle(case):
     parity_cases.fused_path_against_numpy_oracle("cuda", *case)
 
