@@ -940,6 +940,36 @@ k_blur_xy_stream(const float* __restrict__ in, float* __restrict__ out, const fl
 // per touched corner (cmask [B,N,4] bytes: byte k*2+j, bit l).
 // ===========================================================================
 
+// Plane occupancy: plane z of a view holds trilinear mass iff a valid point sits in depth cell z-1
+// or z, i.e. zstart[z+1] > zstart[max(z-1,0)].  k_zsort packs that into DPC_LIVE_WORDS x 32 bits per
+// view; planes without mass are never written by k_splat_xy nor read by k_zfwd, and the planes
+// k_gather_yx skips (same test) are never written by k_zbwd.  Objects rarely span the whole depth
+// range of the lattice, so a sizeable share of the planes is free.
+#define DPC_LIVE_WORDS 8   // Dz <= 256
+__device__ __forceinline__ unsigned live_word(const int* zs, int Dz, int w) {
+  unsigned bits = 0;
+  for (int j = 0; j < 32; ++j) {
+    const int z = w * 32 + j;
+    if (z < Dz && zs[z + 1] > zs[z > 0 ? z - 1 : 0]) bits |= 1u << j;
+  }
+  return bits;
+}
+struct LiveMask {
+  unsigned w[DPC_LIVE_WORDS];
+  // live == nullptr: every plane counts as occupied (dense producers / consumers)
+  __device__ __forceinline__ void load(const unsigned* __restrict__ live, int b) {
+#pragma unroll
+    for (int k = 0; k < DPC_LIVE_WORDS; ++k) w[k] = live ? live[(size_t)b * DPC_LIVE_WORDS + k] : 0xffffffffu;
+  }
+  __device__ __forceinline__ bool operator()(int z) const {   // wave-uniform: b is a block index
+    const int i = z >> 5;
+    unsigned word = 0;
+#pragma unroll
+    for (int k = 0; k < DPC_LIVE_WORDS; ++k) word = (i == k) ? w[k] : word;
+    return (word >> (z & 31)) & 1u;
+  }
+};
+
 // In-place exclusive prefix sum of h[0..M) over the work-group, total into h[M] (M <= a few hundred:
 // the per-view depth-cell histogram).  Every thread of the block must call it; ends with a barrier.
 __device__ __forceinline__ void block_exclusive_scan(int* h, int M) {
@@ -973,7 +1003,7 @@ template <bool QUAT>
 __global__ void __launch_bounds__(1024)
 k_zsort(DpcShape S, DpcParams P, const float* __restrict__ pc, const float* __restrict__ pose,
         const float* __restrict__ trans, const float* __restrict__ focal, float* __restrict__ tr_pc,
-        int* __restrict__ order, int* __restrict__ zstart) {
+        int* __restrict__ order, int* __restrict__ zstart, unsigned* __restrict__ live) {
   DPC_DYN_SMEM(int, hist);  // [Dz + 2]
   const int b = blockIdx.x;
   const int N = S.N, Dz = S.Dz, D = S.D;
@@ -1016,6 +1046,7 @@ k_zsort(DpcShape S, DpcParams P, const float* __restrict__ pc, const float* __re
     __syncthreads();
     block_exclusive_scan(hist, Dz + 1);
     for (int i = tid; i < Dz + 2; i += nth) zstart[(size_t)b * (Dz + 2) + i] = hist[i];
+    if (tid < DPC_LIVE_WORDS) live[(size_t)b * DPC_LIVE_WORDS + tid] = live_word(hist, Dz, tid);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < PB; ++u) {
@@ -1039,6 +1070,7 @@ k_zsort(DpcShape S, DpcParams P, const float* __restrict__ pc, const float* __re
   __syncthreads();
   block_exclusive_scan(hist, Dz + 1);
   for (int i = tid; i < Dz + 2; i += nth) zstart[(size_t)b * (Dz + 2) + i] = hist[i];
+  if (tid < DPC_LIVE_WORDS) live[(size_t)b * DPC_LIVE_WORDS + tid] = live_word(hist, Dz, tid);
   __syncthreads();
   for (int n = tid; n < N; n += nth) {  // tr_pc rows written above by this same work-group
     const Cell c = locate(tp[3 * n], tp[3 * n + 1], tp[3 * n + 2], Dz, D);
@@ -1053,7 +1085,7 @@ __global__ void __launch_bounds__(DPC_BLOCK)
 k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ order,
            const int* __restrict__ zstart, const float* __restrict__ taps_x,
            const float* __restrict__ taps_y, float* __restrict__ out, unsigned char* __restrict__ cmask,
-           int SH, int nstrips, int lr_shift) {
+           int SH, int nstrips, int lr_shift, int skip_empty) {
   DPC_DYN_SMEM(float, tile);
   constexpr int h = KC / 2;
   constexpr int G = zgroup(KC);
@@ -1068,6 +1100,7 @@ k_splat_xy(DpcShape S, const float* __restrict__ tr_pc, const int* __restrict__ 
 
   const int* zs = zstart + (size_t)b * (Dz + 2);
   const int lo = zs[z > 0 ? z - 1 : 0], mid = zs[z], hi = zs[z + 1];
+  if (skip_empty && hi == lo) return;  // no mass in this plane: the live-mask consumer never reads it
   const float* tp = tr_pc + (size_t)b * N * 3;
 
   // 0. sparsity: point clouds are surfaces, most (plane, strip) tiles see no point at all.
@@ -1463,8 +1496,10 @@ __global__ void __launch_bounds__(DPC_BLOCK)
 k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps,
        const float* __restrict__ scale, float* __restrict__ g2_out, float* __restrict__ probs,
        float* __restrict__ proj, float* __restrict__ depth, double* __restrict__ sums, int B, int Dz,
-       int D, int clip_in, int flip_h) {
+       int D, int clip_in, int flip_h, const unsigned* __restrict__ live) {
   const int b = blockIdx.y;
+  LiveMask lm;
+  lm.load(live, b);
   const int ncol = D * D;
   const int col = (blockIdx.x * blockDim.x + threadIdx.x) * CX;
   if (col >= ncol) return;
@@ -1523,11 +1558,20 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
   };
   // two groups of planes in flight, roles alternate (no register copies)
   float bufA[G][CX], bufB[G][CX];
+  // planes without mass were never written by the producer: substitute zeros (uniform branch)
+  auto fetch = [&](int t, float (&v)[CX]) {
+    if (!live || (t < Dz && lm(t))) {
+      zload<CX>(in + base, ncol, t, Dz, v);
+    } else {
 #pragma unroll
-  for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, u, Dz, bufA[u]);
+      for (int c = 0; c < CX; ++c) v[c] = 0.f;
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < G; ++u) fetch(u, bufA[u]);
   for (int t0 = 0; t0 < T; t0 += G) {
 #pragma unroll
-    for (int u = 0; u < G; ++u) zload<CX>(in + base, ncol, t0 + G + u, Dz, bufB[u]);
+    for (int u = 0; u < G; ++u) fetch(t0 + G + u, bufB[u]);
     process(bufA, t0);
 #pragma unroll
     for (int u = 0; u < G; ++u)
@@ -1567,8 +1611,10 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
        const float* __restrict__ scale, const double* __restrict__ sums,
        const float* __restrict__ dproj, const float* __restrict__ ddepth,
        const float* __restrict__ dprobs, float* __restrict__ dgz, float* __restrict__ dscale, int B,
-       int Dz, int D, int flip_h) {
+       int Dz, int D, int flip_h, const unsigned* __restrict__ live) {
   const int b = blockIdx.y;
+  LiveMask lm;
+  lm.load(live, b);
   const int ncol = D * D;
   const int col = (blockIdx.x * blockDim.x + threadIdx.x) * CX;
   const bool active = col < ncol;
@@ -1666,7 +1712,8 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
             for (int c = 0; c < CX; ++c) dg2[c] = 0.f;
           }
           fir.push(dg2, o, u);
-          if (j >= h) store_cx<CX>(dgz + base + (size_t)(j - h) * ncol, o);
+          // planes without points are not read by k_gather_yx (same test): leave them unwritten
+          if (j >= h && (!live || lm(j - h))) store_cx<CX>(dgz + base + (size_t)(j - h) * ncol, o);
         }
       }
     };
@@ -1929,13 +1976,13 @@ int launch_blur_z(hipStream_t st, const DpcShape& S, const float* in, float* out
 // in -> (z-FIR Kz) -> collapse.  Kz must be z_fixed().
 int launch_zfwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const float* in, const float* tz,
                 int Kz, const float* scale, float* g2_out, float* probs, float* proj, float* depth,
-                double* sums, int clip_in, int flip_h) {
+                double* sums, int clip_in, int flip_h, const unsigned* live = nullptr) {
   const dim3 block(DPC_BLOCK, 1, 1);
   const int cx = pick_cx(S.D);
   const dim3 grid = col_grid(S, cx);
 #define DPC_M(KC, CXV)                                                                                \
   DPC_LAUNCH("zfwd", (k_zfwd<KC, CXV>), grid, block, 0, st, P, in, (Kz > 0 ? tz : (const float*)nullptr), scale, \
-             g2_out, probs, proj, depth, sums, S.B, S.Dz, S.D, clip_in, flip_h)
+             g2_out, probs, proj, depth, sums, S.B, S.Dz, S.D, clip_in, flip_h, live)
   DPC_Z_DISPATCH(Kz, cx, DPC_M);
 #undef DPC_M
   return last_error();
@@ -1943,13 +1990,13 @@ int launch_zfwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const flo
 
 int launch_zbwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const float* g2, const float* tz,
                 int Kz, const float* scale, const double* sums, const float* dproj, const float* ddepth,
-                const float* dprobs, float* dgz, float* dscale, int flip_h) {
+                const float* dprobs, float* dgz, float* dscale, int flip_h, const unsigned* live = nullptr) {
   const dim3 block(DPC_BLOCK, 1, 1);
   const int cx = pick_cx(S.D);
   const dim3 grid = col_grid(S, cx);
 #define DPC_M(KC, CXV)                                                                                \
   DPC_LAUNCH("zbwd", (k_zbwd<KC, CXV>), grid, block, 0, st, P, g2, (Kz > 0 ? tz : (const float*)nullptr), scale, \
-             sums, dproj, ddepth, dprobs, dgz, dscale, S.B, S.Dz, S.D, flip_h)
+             sums, dproj, ddepth, dprobs, dgz, dscale, S.B, S.Dz, S.D, flip_h, live)
   DPC_Z_DISPATCH(Kz, cx, DPC_M);
 #undef DPC_M
   return last_error();
@@ -2045,7 +2092,9 @@ SplatPlan splat_plan(const DpcShape& S) {
   p.lds_bytes = sizeof(float) * (size_t)(SH + 2 * (K / 2)) * (D + 1);  // tile + per-row flags
   return p;
 }
-inline size_t point_index_ints(const DpcShape& S) { return (size_t)S.B * S.N + (size_t)S.B * (S.Dz + 2); }
+inline size_t point_index_ints(const DpcShape& S) {
+  return (size_t)S.B * S.N + (size_t)S.B * (S.Dz + 2) + (size_t)S.B * DPC_LIVE_WORDS;
+}
 inline size_t parts_bytes(const DpcShape& S) { return align256(sizeof(float) * 12 * (size_t)S.B * S.N); }
 
 int launch_gather_yx(hipStream_t st, const DpcShape& S, const SplatPlan& pl, const float* dgz, const float* tr_pc,
@@ -2075,21 +2124,22 @@ int launch_gather_yx(hipStream_t st, const DpcShape& S, const SplatPlan& pl, con
 
 int launch_splat_xy(hipStream_t st, const DpcShape& S, const DpcParams& P, const SplatPlan& pl, const float* pc,
                     const float* pose, const float* trans, const float* focal, float* tr_pc, int* order,
-                    int* zstart, const float* tx, const float* ty, float* out, unsigned char* cmask) {
+                    int* zstart, const float* tx, const float* ty, float* out, unsigned char* cmask,
+                    unsigned* live, bool skip_empty) {
   int zt = 64;
   while (zt < 1024 && zt < S.N) zt <<= 1;
   if (P.pose_is_quaternion)
     DPC_LAUNCH("zsort", (k_zsort<true>), dim3(S.B, 1, 1), dim3(zt, 1, 1), sizeof(int) * (size_t)(S.Dz + 2), st, S, P,
-               pc, pose, trans, focal, tr_pc, order, zstart);
+               pc, pose, trans, focal, tr_pc, order, zstart, live);
   else
     DPC_LAUNCH("zsort", (k_zsort<false>), dim3(S.B, 1, 1), dim3(zt, 1, 1), sizeof(int) * (size_t)(S.Dz + 2), st, S, P,
-               pc, pose, trans, focal, tr_pc, order, zstart);
+               pc, pose, trans, focal, tr_pc, order, zstart, live);
   const long long nblk = (long long)S.B * S.Dz * pl.nstrips;
   if (nblk > 0x7fffffffLL) return DPC_E_SHAPE;
   const dim3 grid((unsigned)nblk, 1, 1), block(DPC_BLOCK, 1, 1);
 #define DPC_SP(KC, VY)                                                                                     \
   DPC_LAUNCH("splat_xy", (k_splat_xy<KC, VY>), grid, block, pl.lds_bytes, st, S, tr_pc, (const int*)order, \
-             (const int*)zstart, tx, ty, out, cmask, pl.SH, pl.nstrips, pl.lr_shift)
+             (const int*)zstart, tx, ty, out, cmask, pl.SH, pl.nstrips, pl.lr_shift, skip_empty ? 1 : 0)
 #define DPC_SPV(KC)                \
   do {                             \
     if (pl.vy == 2) DPC_SP(KC, 2); \
@@ -2657,12 +2707,15 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
 
   const float* zin;
   int clip_in;
+  unsigned* live = nullptr;
   if (plan.ok) {
     // 1+2 fused front end: transform + z-bucket (one WG per view) -> per-plane LDS splat + clip + x,y blur
     int* order = (int*)point_index;                  // [B,N]   points sorted by depth cell
     int* zstart = order + (size_t)S.B * S.N;         // [B,Dz+2] bucket starts
+    live = (unsigned*)(zstart + (size_t)S.B * (S.Dz + 2));   // [B,8] plane-occupancy bits
+    // planes without mass are skipped end to end when the consumer is the mask-aware k_zfwd
     rc = launch_splat_xy(st, S, P, plan, pc, pose, trans, focal, tr_pc, order, zstart, taps_x, taps_y, tmp,
-                         clip_mask);
+                         clip_mask, live, drc && z_fixed(S.Kz));
     if (rc) return rc;
     zin = tmp;
     clip_in = 0;
@@ -2689,7 +2742,7 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   // 3. z blur fused with the ray collapse
   if (drc && z_fixed(S.Kz))
     return launch_zfwd(st, S, P, zin, taps_z, S.Kz, scale, grid_blur, nullptr, proj, proj_depth, ray_sums,
-                       clip_in, 1);
+                       clip_in, 1, live);
   // generic tap count or max-collapse: materialise G2, then collapse separately
   if (S.Kz > 0) {
     if (clip_in) return DPC_E_MODE;  // z-only blur of the raw grid is not a reference configuration
@@ -2747,9 +2800,12 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   if (e != hipSuccess) return (int)e;
   float* ds_acc = scale ? accum : nullptr;
   // 1. collapse VJP (+ z-FIR adjoint) -> tA
+  const bool yx = use_cmask && plan.gSH > 0;   // consumer of tA is k_gather_yx (reads occupied planes only)
   if (drc && z_fixed(S.Kz)) {
+    const unsigned* live =
+        yx ? (const unsigned*)(point_index + (size_t)S.B * S.N + (size_t)S.B * (S.Dz + 2)) : nullptr;
     rc = launch_zbwd(st, S, P, grid_blur, taps_z, S.Kz, scale, ray_sums, dproj, dproj_depth, nullptr, tA,
-                     ds_acc, 1);
+                     ds_acc, 1, live);
     if (rc) return rc;
   } else {
     float* first = (S.Kz > 0) ? tB : tA;
@@ -2767,7 +2823,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
       if (rc) return rc;
     }
   }
-  if (use_cmask && plan.gSH > 0) {
+  if (yx) {
     // 2+3 fused: per-plane LDS pass (y-blur + sparse x-blur + clip bits + trilinear gather),
     // then the camera-transform VJP over the per-corner partials
     const int* order = (const int*)point_index;

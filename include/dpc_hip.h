@@ -84,9 +84,10 @@ int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, 
  * (generic path: zero-fill + global float atomics); bit 1 (value 2) = clip_mask
  * [B,N,4] bytes, one bit per touched trilinear corner (fused path: points are
  * bucketed by depth cell and splatted into per-plane LDS tiles, the raw grid
- * never reaches HBM); bit 2 (value 4) = point_index, int32 [B*N + B*(Dz+2)]: the
- * points of each view sorted by depth cell followed by the bucket starts, which
- * the backward's per-plane gather re-uses (set together with bit 1).  Buffers
+ * never reaches HBM); bit 2 (value 4) = point_index, int32
+ * [B*N + B*(Dz+2) + B*8]: the points of each view sorted by depth cell, the
+ * bucket starts, and 8 words of plane-occupancy bits per view, which the
+ * backward re-uses (set together with bit 1).  Buffers
  * that are not used may be null.  <0 on error. */
 int dpc_saved_layout(const DpcShape* shape, const DpcParams* params);
 
