@@ -946,13 +946,17 @@ k_blur_xy_stream(const float* __restrict__ in, float* __restrict__ out, const fl
 // k_gather_yx skips (same test) are never written by k_zbwd.  Objects rarely span the whole depth
 // range of the lattice, so a sizeable share of the planes is free.
 #define DPC_LIVE_WORDS 8   // Dz <= 256
-__device__ __forceinline__ unsigned live_word(const int* zs, int Dz, int w) {
-  unsigned bits = 0;
-  for (int j = 0; j < 32; ++j) {
-    const int z = w * 32 + j;
-    if (z < Dz && zs[z + 1] > zs[z > 0 ? z - 1 : 0]) bits |= 1u << j;
+// every thread of the work-group calls; zs = the view's bucket starts in LDS
+__device__ __forceinline__ void write_live_words(const int* zs, int Dz, unsigned* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (blockDim.x + 63) >> 6;
+  for (int z0 = wave * 64; z0 < 32 * DPC_LIVE_WORDS; z0 += nwave * 64) {
+    const int z = z0 + lane;
+    const unsigned long long m = __ballot(z < Dz && zs[(z < Dz ? z : 0) + 1] > zs[(z > 0 && z < Dz) ? z - 1 : 0]);
+    if (lane == 0) {
+      out[z0 >> 5] = (unsigned)m;
+      out[(z0 >> 5) + 1] = (unsigned)(m >> 32);
+    }
   }
-  return bits;
 }
 struct LiveMask {
   unsigned w[DPC_LIVE_WORDS];
@@ -961,12 +965,19 @@ struct LiveMask {
 #pragma unroll
     for (int k = 0; k < DPC_LIVE_WORDS; ++k) w[k] = live ? live[(size_t)b * DPC_LIVE_WORDS + k] : 0xffffffffu;
   }
-  __device__ __forceinline__ bool operator()(int z) const {   // wave-uniform: b is a block index
-    const int i = z >> 5;
-    unsigned word = 0;
+  // occupancy bits of planes s .. s+31 (bit u = plane s+u; planes outside [0, 32*DPC_LIVE_WORDS) read 0).
+  // Uniform over the block (b is a block index): pinned to a scalar register, so that the per-plane
+  // tests `(win >> u) & 1` with compile-time u cost one scalar op each.
+  __device__ __forceinline__ unsigned window(int s) const {
+    const int i = s >> 5, sft = s & 31;
+    unsigned lo = 0, hi = 0;
 #pragma unroll
-    for (int k = 0; k < DPC_LIVE_WORDS; ++k) word = (i == k) ? w[k] : word;
-    return (word >> (z & 31)) & 1u;
+    for (int k = 0; k < DPC_LIVE_WORDS; ++k) {
+      lo = (i == k) ? w[k] : lo;
+      hi = (i + 1 == k) ? w[k] : hi;
+    }
+    const unsigned r = sft ? ((lo >> sft) | (hi << (32 - sft))) : lo;
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)r);
   }
 };
 
@@ -1046,7 +1057,7 @@ k_zsort(DpcShape S, DpcParams P, const float* __restrict__ pc, const float* __re
     __syncthreads();
     block_exclusive_scan(hist, Dz + 1);
     for (int i = tid; i < Dz + 2; i += nth) zstart[(size_t)b * (Dz + 2) + i] = hist[i];
-    if (tid < DPC_LIVE_WORDS) live[(size_t)b * DPC_LIVE_WORDS + tid] = live_word(hist, Dz, tid);
+    write_live_words(hist, Dz, live + (size_t)b * DPC_LIVE_WORDS);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < PB; ++u) {
@@ -1070,7 +1081,7 @@ k_zsort(DpcShape S, DpcParams P, const float* __restrict__ pc, const float* __re
   __syncthreads();
   block_exclusive_scan(hist, Dz + 1);
   for (int i = tid; i < Dz + 2; i += nth) zstart[(size_t)b * (Dz + 2) + i] = hist[i];
-  if (tid < DPC_LIVE_WORDS) live[(size_t)b * DPC_LIVE_WORDS + tid] = live_word(hist, Dz, tid);
+  write_live_words(hist, Dz, live + (size_t)b * DPC_LIVE_WORDS);
   __syncthreads();
   for (int n = tid; n < N; n += nth) {  // tr_pc rows written above by this same work-group
     const Cell c = locate(tp[3 * n], tp[3 * n + 1], tp[3 * n + 2], Dz, D);
@@ -1559,19 +1570,24 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
   // two groups of planes in flight, roles alternate (no register copies)
   float bufA[G][CX], bufB[G][CX];
   // planes without mass were never written by the producer: substitute zeros (uniform branch)
-  auto fetch = [&](int t, float (&v)[CX]) {
-    if (!live || (t < Dz && lm(t))) {
+  static_assert(G <= 32, "one occupancy window per group of planes");
+  auto fetch = [&](unsigned win, int u, int t, float (&v)[CX]) {
+    if (!live || ((win >> u) & 1u)) {
       zload<CX>(in + base, ncol, t, Dz, v);
     } else {
 #pragma unroll
       for (int c = 0; c < CX; ++c) v[c] = 0.f;
     }
   };
+  {
+    const unsigned win = lm.window(0);
 #pragma unroll
-  for (int u = 0; u < G; ++u) fetch(u, bufA[u]);
+    for (int u = 0; u < G; ++u) fetch(win, u, u, bufA[u]);
+  }
   for (int t0 = 0; t0 < T; t0 += G) {
+    const unsigned win = lm.window(t0 + G);
 #pragma unroll
-    for (int u = 0; u < G; ++u) fetch(t0 + G + u, bufB[u]);
+    for (int u = 0; u < G; ++u) fetch(win, u, t0 + G + u, bufB[u]);
     process(bufA, t0);
 #pragma unroll
     for (int u = 0; u < G; ++u)
@@ -1677,6 +1693,7 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
     const int T = Dz + h;
     // rem = total - sum_{i<=j} a_i, kept in float64 (no cancellation error)
     auto process = [&](const float (&buf)[G][CX], int t0) {
+      const unsigned swin = lm.window(t0 - h);   // bit u: output plane t0 + u - h is read by k_gather_yx
 #pragma unroll
       for (int u = 0; u < G; ++u) {
         const int j = t0 + u;
@@ -1713,7 +1730,7 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
           }
           fir.push(dg2, o, u);
           // planes without points are not read by k_gather_yx (same test): leave them unwritten
-          if (j >= h && (!live || lm(j - h))) store_cx<CX>(dgz + base + (size_t)(j - h) * ncol, o);
+          if (j >= h && (!live || ((swin >> u) & 1u))) store_cx<CX>(dgz + base + (size_t)(j - h) * ncol, o);
         }
       }
     };

@@ -161,6 +161,7 @@ static inline float __shfl_xor(float v, int mask, int width = 64) {
 }
 
 static inline float __fdividef(float a, float b) { return a / b; }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only used on wave-uniform values
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
   memset(p, v, n);
   return hipSuccess;
