@@ -46,6 +46,7 @@ def build_case(cfg_id, B, device, seed_offset=0, kind="shell"):
                 kern=dpc_amd.smoothing_kernel(cfg, c["sigma"], device=device),
                 gt=torch.tensor(dpc_amd.synthetic.disk_gt(c["B"], c["D"]), device=device),
                 B=c["B"], N=c["N"], D=c["D"], K=c["K"], sigma=c["sigma"])
+    case["gt_neg_over_b"] = -case["gt"] / c["B"]        # constant input: -gt / B
     return case
 
 
@@ -53,7 +54,7 @@ def step(case):
     out = dpc_amd.pointcloud_project_fast(case["cfg"], case["pc"], case["pose"], None, None, case["kern"],
                                           scaling_factor=case["scale"])
     proj = out["proj"]
-    dproj = (proj.detach() - case["gt"]) / case["B"]
+    dproj = torch.add(case["gt_neg_over_b"], proj.detach(), alpha=1.0 / case["B"])   # (proj - gt) / B, one launch
     return torch.autograd.grad(proj, [case["pc"], case["pose"], case["scale"]], dproj)
 
 

@@ -614,11 +614,20 @@ template <bool QUAT>
 __global__ void k_pose_finalize(DpcShape S, DpcParams P, const float* __restrict__ pose,
                                 const float* __restrict__ accum, float* __restrict__ dpose,
                                 float* __restrict__ dtrans, float* __restrict__ dfocal,
-                                float* __restrict__ dscale /*nullable: from accumulator slot 15*/) {
+                                float* __restrict__ dscale /*nullable: from accumulator slot 15 or the partials*/,
+                                const float* __restrict__ dsparts /*nullable: [B,nzb] from k_zbwd*/, int nzb) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= S.B) return;
   const float* a = accum + 16 * b;
-  if (dscale) dscale[b] = a[15];
+  if (dscale) {
+    float ds = 0.f;
+    if (dsparts) {
+      for (int i = 0; i < nzb; ++i) ds += dsparts[(size_t)b * nzb + i];
+    } else {
+      ds = a[15];
+    }
+    dscale[b] = ds;
+  }
   if (QUAT) {
     const float* q = pose + 4 * b;
     const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
@@ -1627,8 +1636,12 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
        const float* __restrict__ scale, const double* __restrict__ sums,
        const float* __restrict__ dproj, const float* __restrict__ ddepth,
        const float* __restrict__ dprobs, float* __restrict__ dgz, float* __restrict__ dscale, int B,
-       int Dz, int D, int flip_h, const unsigned* __restrict__ live) {
+       int Dz, int D, int flip_h, const unsigned* __restrict__ live, float* __restrict__ dsparts,
+       float* __restrict__ accum_zero) {
   const int b = blockIdx.y;
+  // first kernel of the fused backward: its first work-group per view clears the view's [16]
+  // pose accumulator for k_points_bwd (saves a memset launch)
+  if (accum_zero && blockIdx.x == 0 && threadIdx.x < 16) accum_zero[16 * (size_t)b + threadIdx.x] = 0.f;
   LiveMask lm;
   lm.load(live, b);
   const int ncol = D * D;
@@ -1747,7 +1760,10 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
         for (int c = 0; c < CX; ++c) bufA[u][c] = bufB[u][c];
     }
   }
-  if (dscale) {  // uniform across the grid
+  if (dsparts) {  // uniform across the grid: one partial per work-group, summed in fixed order by k_pose_finalize
+    block_reduce_sum<1>(dsacc);
+    if (threadIdx.x == 0) dsparts[(size_t)b * gridDim.x + blockIdx.x] = dsacc[0];
+  } else if (dscale) {
     block_reduce_sum<1>(dsacc);
     if (threadIdx.x == 0) atomicAdd(dscale + 16 * (size_t)b + 15, dsacc[0]);  // [B,16] accumulator, slot 15
   }
@@ -2007,13 +2023,14 @@ int launch_zfwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const flo
 
 int launch_zbwd(hipStream_t st, const DpcShape& S, const DpcParams& P, const float* g2, const float* tz,
                 int Kz, const float* scale, const double* sums, const float* dproj, const float* ddepth,
-                const float* dprobs, float* dgz, float* dscale, int flip_h, const unsigned* live = nullptr) {
+                const float* dprobs, float* dgz, float* dscale, int flip_h, const unsigned* live = nullptr,
+                float* dsparts = nullptr, float* accum_zero = nullptr) {
   const dim3 block(DPC_BLOCK, 1, 1);
   const int cx = pick_cx(S.D);
   const dim3 grid = col_grid(S, cx);
 #define DPC_M(KC, CXV)                                                                                \
   DPC_LAUNCH("zbwd", (k_zbwd<KC, CXV>), grid, block, 0, st, P, g2, (Kz > 0 ? tz : (const float*)nullptr), scale, \
-             sums, dproj, ddepth, dprobs, dgz, dscale, S.B, S.Dz, S.D, flip_h, live)
+             sums, dproj, ddepth, dprobs, dgz, dscale, S.B, S.Dz, S.D, flip_h, live, dsparts, accum_zero)
   DPC_Z_DISPATCH(Kz, cx, DPC_M);
 #undef DPC_M
   return last_error();
@@ -2023,7 +2040,8 @@ int launch_points_bwd(hipStream_t st, const DpcShape& S, const DpcParams& P, con
                       const float* pose, const float* trans, const float* focal, const float* tr_pc,
                       const float* dgrid, const float* mask, const unsigned char* cmask, const float* taps_x,
                       const float* dtr_in, const float* parts, bool gather, float* dpc, float* dpose,
-                      float* dtrans, float* dfocal, float* dscale, float* accum, bool zero_accum) {
+                      float* dtrans, float* dfocal, float* dscale, float* accum, bool zero_accum,
+                      const float* dsparts = nullptr, int nzb = 0) {
   if (zero_accum) {
     hipError_t e = dpc_memset("memset_small", accum, sizeof(float) * 16 * (size_t)S.B, st);
     if (e != hipSuccess) return (int)e;
@@ -2050,10 +2068,10 @@ int launch_points_bwd(hipStream_t st, const DpcShape& S, const DpcParams& P, con
   const dim3 fg((S.B + 63) / 64, 1, 1), fb(64, 1, 1);
   if (quat)
     DPC_LAUNCH("pose_finalize", (k_pose_finalize<true>), fg, fb, 0, st, S, P, pose, accum, dpose, dtrans, dfocal,
-               dscale);
+               dscale, dsparts, nzb);
   else
     DPC_LAUNCH("pose_finalize", (k_pose_finalize<false>), fg, fb, 0, st, S, P, pose, accum, dpose, dtrans, dfocal,
-               dscale);
+               dscale, dsparts, nzb);
   return last_error();
 }
 
@@ -2113,6 +2131,9 @@ inline size_t point_index_ints(const DpcShape& S) {
   return (size_t)S.B * S.N + (size_t)S.B * (S.Dz + 2) + (size_t)S.B * DPC_LIVE_WORDS;
 }
 inline size_t parts_bytes(const DpcShape& S) { return align256(sizeof(float) * 12 * (size_t)S.B * S.N); }
+// per-work-group dscale partials of k_zbwd: [B, work-groups per view]
+inline int zbwd_blocks(const DpcShape& S) { return (int)col_grid(S, pick_cx(S.D)).x; }
+inline size_t dsparts_bytes(const DpcShape& S) { return align256(sizeof(float) * (size_t)S.B * zbwd_blocks(S)); }
 
 int launch_gather_yx(hipStream_t st, const DpcShape& S, const SplatPlan& pl, const float* dgz, const float* tr_pc,
                      const int* order, const int* zstart, const unsigned char* cmask, const float* tx,
@@ -2555,7 +2576,7 @@ size_t dpc_workspace_bytes(const DpcShape* shape, int direction) {
   if (check_shape(shape, false) != DPC_OK) return 0;
   const size_t g = align256(grid_elems(*shape) * sizeof(float));
   const size_t acc = align256(sizeof(float) * 16 * (size_t)shape->B);
-  return direction == 0 ? g : 2 * g + acc + parts_bytes(*shape);
+  return direction == 0 ? g : 2 * g + acc + parts_bytes(*shape) + dsparts_bytes(*shape);
 }
 
 int dpc_transform_fwd(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* pc,
@@ -2813,16 +2834,21 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   float* accum = (float*)((char*)workspace + 2 * gbytes);  // [B,16]: pose/trans/focal sums, slot 15 = dscale
   float* parts = (float*)((char*)accum + align256(sizeof(float) * 16 * (size_t)S.B));  // [B,N,4,3]
 
-  hipError_t e = dpc_memset("memset_small", accum, sizeof(float) * 16 * (size_t)S.B, st);
-  if (e != hipSuccess) return (int)e;
+  float* dsparts = (float*)((char*)parts + parts_bytes(S));   // [B, zbwd work-groups]: dscale partials
+  const bool zfused = drc && z_fixed(S.Kz);
+  if (!zfused) {  // (the fused z kernel clears the accumulator itself and returns dscale as partials)
+    hipError_t e = dpc_memset("memset_small", accum, sizeof(float) * 16 * (size_t)S.B, st);
+    if (e != hipSuccess) return (int)e;
+  }
   float* ds_acc = scale ? accum : nullptr;
+  const int nzb = zbwd_blocks(S);
   // 1. collapse VJP (+ z-FIR adjoint) -> tA
   const bool yx = use_cmask && plan.gSH > 0;   // consumer of tA is k_gather_yx (reads occupied planes only)
-  if (drc && z_fixed(S.Kz)) {
+  if (zfused) {
     const unsigned* live =
         yx ? (const unsigned*)(point_index + (size_t)S.B * S.N + (size_t)S.B * (S.Dz + 2)) : nullptr;
     rc = launch_zbwd(st, S, P, grid_blur, taps_z, S.Kz, scale, ray_sums, dproj, dproj_depth, nullptr, tA,
-                     ds_acc, 1, live);
+                     ds_acc, 1, live, scale ? dsparts : nullptr, accum);
     if (rc) return rc;
   } else {
     float* first = (S.Kz > 0) ? tB : tA;
@@ -2849,7 +2875,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
     if (rc) return rc;
     return launch_points_bwd(st, S, P, pc, pose, trans, focal, tr_pc, nullptr, nullptr, nullptr, nullptr,
                              dtr_pc_in, parts, false, dpc, dpose, dtrans, dfocal, scale ? dscale : nullptr,
-                             accum, false);
+                             accum, false, (zfused && scale) ? dsparts : nullptr, nzb);
   }
   // 2. y-blur adjoint (dense) -> tB ; the x-blur is evaluated sparsely in step 3
   const float* dg = tA;
@@ -2861,7 +2887,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   // 3. sparse x-blur + clip mask + gather + transform VJP + reductions
   return launch_points_bwd(st, S, P, pc, pose, trans, focal, tr_pc, dg, use_cmask ? nullptr : grid_raw,
                            use_cmask ? clip_mask : nullptr, taps_x, dtr_pc_in, nullptr, true, dpc, dpose, dtrans,
-                           dfocal, scale ? dscale : nullptr, accum, false);
+                           dfocal, scale ? dscale : nullptr, accum, false, (zfused && scale) ? dsparts : nullptr, nzb);
 }
 
 int dpc_silhouette_loss_fwd(dpc_stream_t stream, int B, int C, int D, int S, const float* proj, const float* gt,
