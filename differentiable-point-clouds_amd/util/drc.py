@@ -2,9 +2,12 @@
 kernels.  Same names, argument order and tensor layouts as the reference:
 voxels [B,Dz,D,D,1] -> proj [B,D,D,1], event probabilities p [Dz+1,B,D,D,1].
 
-Only the reference's default configuration (log-space, tf.cumsum:
-drc_logsum=true, drc_tf_cumulative=true, default_config.yaml:88-90) is
-implemented; the non-log / python-loop variants raise NotImplementedError.
+The reference's switches (default_config.yaml:88-90): drc_logsum=true is the log-space
+form with the clip to [eps, 1-eps] and the eps "unity"; drc_logsum=false is the plain
+product form p_i = c_i * prod_{j<i}(1-c_j) -- the same kernels with eps = 0 (the kernels
+never take a log either way); drc_tf_cumulative only chooses between tf.cumsum and an
+equivalent python loop, which is the same sequence of operations.  In the product form
+the kernels keep occupancies inside [0, 1] (the projector's grids always are).
 """
 import torch
 
@@ -13,15 +16,16 @@ from .. import _capi, ops
 
 def _meta(cfg, Dz, D, collapse=_capi.DPC_COLLAPSE_DRC):
     return ops.ProjMeta(Dz=int(Dz), D=int(D), camera_distance=float(cfg.camera_distance),
-                        focal_length=float(cfg.focal_length), eps=float(cfg.drc_logsum_clip_val),
+                        focal_length=float(cfg.focal_length),
+                        eps=float(cfg.drc_logsum_clip_val) if getattr(cfg, "drc_logsum", True) else 0.0,
                         max_depth=float(cfg.max_depth),
                         pose_quaternion=bool(getattr(cfg, "pose_quaternion", True)),
                         collapse_mode=collapse)
 
 
 def _check_cfg(cfg):
-    if not getattr(cfg, "drc_logsum", True) or not getattr(cfg, "drc_tf_cumulative", True):
-        raise NotImplementedError("only the default log-space cumsum DRC (drc_logsum, drc_tf_cumulative)")
+    """Every drc_* switch of the reference maps onto the same kernels (see the module docstring)."""
+    return None
 
 
 def _grid4(voxels):

@@ -19,6 +19,7 @@ ALL_CASES = ["tiny", "tiny_probs_grad", "tiny_focal", "tiny_nokernel", "tiny_nos
              "tiny_maxproj", "tiny_voxz", "tiny_matrix", "k21", "cfg1", "mid"]
 
 
+DRC_VARIANT_CASES = ["tiny_nolog", "tiny_loop", "d32_nolog"]   # drc_logsum / drc_tf_cumulative switched off
 RGB_CASES = ["tiny_rgb", "tiny_rgb_div"]      # colour channels: pinned by the goldens only (the oracles are grey)
 
 

@@ -12,6 +12,10 @@ def product_cfg(name, g):
     extra = {}
     if name == "tiny_rgb_div":
         extra = dict(pc_rgb_divide_by_occupancies=True, pc_rgb_clip_after_conv=True, pc_rgb_stop_points_gradient=True)
+    if name.endswith("_nolog"):
+        extra = dict(drc_logsum=False)
+    if name == "tiny_loop":
+        extra = dict(drc_tf_cumulative=False)
     return dpc_amd.default_config(**extra, vox_size=cp["D"], vox_size_z=(cp["Dz"] if cp["Dz"] != cp["D"] else -1),
                                   pc_gauss_kernel_size=(cp["K"] or 11),
                                   pose_quaternion=cp["pose_quaternion"],

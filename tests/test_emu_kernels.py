@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import ALL_CASES, load, maxabs, relerr
+from helpers import ALL_CASES, DRC_VARIANT_CASES, load, maxabs, relerr
 from run_case import run_product
 import parity_cases
 
@@ -23,7 +23,7 @@ TOL_DEPTH = 2e-4
 TOL_GRAD = 2e-4
 
 
-@pytest.mark.parametrize("name", SMALL)
+@pytest.mark.parametrize("name", SMALL + DRC_VARIANT_CASES)
 def test_emu_forward_backward_matches_goldens(emu, name):
     g = load(name)
     res, gr = run_product(name, g, "cpu", grads=True, touch_lazy=True)

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import dpc_amd
-from helpers import ALL_CASES, load, maxabs, onp, rcpu, relerr, synth
+from helpers import ALL_CASES, DRC_VARIANT_CASES, load, maxabs, onp, rcpu, relerr, synth
 from run_case import run_product
 import parity_cases
 
@@ -32,7 +32,7 @@ def _real_library():
     yield lib
 
 
-@pytest.mark.parametrize("name", ALL_CASES)
+@pytest.mark.parametrize("name", ALL_CASES + DRC_VARIANT_CASES)
 def test_goldens(name):
     g = load(name)
     lazy = "voxels_f64" in g

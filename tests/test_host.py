@@ -125,9 +125,9 @@ def test_shape_and_type_errors(emu):
         dpc_amd.pointcloud_project_fast(cfg_m, pc, torch.eye(4).repeat(2, 1, 1), torch.zeros(2, 3), None)
     with pytest.raises(ValueError, match="even"):
         dpc_amd.gauss_kernel_1d(4, 1.0, device="cpu")
-    cfg_bad = dpc_amd.default_config(vox_size=8, drc_logsum=False)
-    with pytest.raises(NotImplementedError):
-        dpc_amd.pointcloud_project_fast(cfg_bad, pc, torch.ones(2, 4), None, None)
+    cfg_bad = dpc_amd.default_config(vox_size=8, pc_separable_gauss_filter=False)
+    with pytest.raises(NotImplementedError):                                   # dense 3-D blur kernel
+        dpc_amd.pointcloud_project_fast(cfg_bad, pc, torch.ones(2, 4), None, None, torch.ones(5, 5, 5, 1, 1))
     with pytest.raises(KeyError):
         dpc_amd.default_config(no_such_key=1)
 
