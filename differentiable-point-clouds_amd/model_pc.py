@@ -22,6 +22,7 @@ from .util.point_cloud import pc_point_dropout, pointcloud_project, pointcloud_p
 from .util.quaternion import quaternion_conjugate as q_conj
 from .util.quaternion import quaternion_multiply as q_mul
 from .util.quaternion import quaternion_normalise as q_norm
+from .util.quaternion import quaternion_rotate as q_rotate
 
 
 def tf_repeat_0(input, num):  # noqa: A002  (reference name; model_pc.py:23-32)
@@ -59,6 +60,7 @@ class ModelPointCloud(object):
         self._global_step = global_step
         self._device = device
         self.setup_sigma()
+        self.setup_misc()
 
     def cfg(self):
         return self._params
@@ -68,6 +70,13 @@ class ModelPointCloud(object):
         self._sigma_rel = get_smooth_sigma(cfg, self._global_step)
         self._gauss_sigma = self._sigma_rel / cfg.vox_size
         self._gauss_kernel = smoothing_kernel(cfg, self._sigma_rel, device=self._device)
+
+    def setup_misc(self, generator=None):                     # model_pc.py:161-168
+        """Reference cloud of the pose_student_align_loss: 2000 points ~ N(0,1) clipped to +-3
+        (a tf.Variable there; assign `_pc_for_alignloss` to share one across ranks)."""
+        if getattr(self.cfg(), "pose_student_align_loss", False):
+            values = torch.randn(2000, 3, generator=generator).clamp_(-3.0, 3.0)
+            self._pc_for_alignloss = values.to(self._device) if self._device is not None else values
 
     def set_global_step(self, global_step):
         self._global_step = global_step
@@ -165,11 +174,15 @@ class ModelPointCloud(object):
         teachers = outputs["poses"].reshape(-1, C, 4)
         teachers = teachers[torch.arange(teachers.shape[0], device=teachers.device), min_loss].detach()
         weights = inputs["valid_samples"] if cfg.variable_num_views else 1.0
-        if getattr(cfg, "pose_student_align_loss", False):
-            raise NotImplementedError("pose_student_align_loss (off by default)")
-        q_diff = q_norm(q_mul(teachers, q_conj(student)))
-        angle_diff = q_diff[:, 0]
-        student_loss = ((1.0 - angle_diff ** 2) * weights).sum() / float(min_loss.shape[0])
+        if getattr(cfg, "pose_student_align_loss", False):                    # model_pc.py:362-368
+            ref_pc = self._pc_for_alignloss
+            ref_all = ref_pc.unsqueeze(0).expand(teachers.shape[0], -1, -1)
+            diff = q_rotate(ref_all, teachers) - q_rotate(ref_all, student)
+            student_loss = (diff * diff).sum() / 2 / float(ref_pc.shape[0]) / float(min_loss.shape[0])
+        else:
+            q_diff = q_norm(q_mul(teachers, q_conj(student)))
+            angle_diff = q_diff[:, 0]
+            student_loss = ((1.0 - angle_diff ** 2) * weights).sum() / float(min_loss.shape[0])
         return student_loss * cfg.pose_predictor_student_loss_weight
 
     def add_proj_loss(self, inputs, outputs, weight_scale, add_summary=False):   # model_pc.py:383-423

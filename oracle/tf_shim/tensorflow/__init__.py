@@ -340,6 +340,10 @@ def ones(shape, dtype=float32):
     return _wrap(_torch.ones([int(s) for s in shape], dtype=_dt(dtype)))
 
 
+def Variable(initial_value, name=None, dtype=None, trainable=True):  # noqa: N802 (tf name)
+    return _wrap(_torch.as_tensor(initial_value, dtype=_dt(dtype) if dtype is not None else _FLOAT))
+
+
 def zeros(shape, dtype=float32):
     return _wrap(_torch.zeros([int(s) for s in shape], dtype=_dt(dtype)))
 

@@ -134,6 +134,17 @@ def main():
     for k, v in run(torch.float64, inp, cfg_s, gs).items():
         if k in ("loss", "dposes", "dstudent", "dpoints"):
             out["student_" + k + "_f64"] = v
+    # ... and with the alignment form of the student loss (model_pc.py:362-368); the reference draws its
+    # 2000-point reference cloud with the global numpy RNG in setup_misc, so seed it and store the cloud
+    cfg_a = make_cfg(pose_predictor_student=True, pose_predictor_student_loss_weight=20.0, pose_student_align_loss=True)
+    np.random.seed(1234)
+    tf.set_float_dtype(torch.float64)
+    ref_cloud = M.ModelPointCloud(cfg_a, global_step=gs)._pc_for_alignloss.detach().numpy().astype(np.float32)
+    np.random.seed(1234)
+    for k, v in run(torch.float64, inp, cfg_a, gs).items():
+        if k in ("loss", "dposes", "dstudent"):
+            out["align_" + k + "_f64"] = v
+    out["align_ref_cloud"] = ref_cloud
     # schedules (model_pc.py:35-64)
     steps = np.array([0, 1000, 150000, 300000, 599999], dtype=np.int64)
     sig = [float(M.get_smooth_sigma(cfg, int(s))) for s in steps]

@@ -179,3 +179,27 @@ def test_get_loss_all_terms_emulated(emu, name):
 def test_get_loss_all_terms_gpu(name):
     dpc_amd._capi.set_library(None)
     _run_losses("cuda", name)
+
+
+def test_student_align_loss_matches_reference(emu):
+    """pose_student_align_loss (model_pc.py:362-368): teacher and student rotate a fixed reference
+    cloud; the cloud the reference drew is part of the golden."""
+    g = load("caller_toy")
+    cfg = _cfg(g)
+    cfg.pose_predictor_student = True
+    cfg.pose_predictor_student_loss_weight = 20.0
+    cfg.pose_student_align_loss = True
+    model = M.ModelPointCloud(cfg, global_step=int(g["global_step"]), device="cpu")
+    assert model._pc_for_alignloss.shape == (2000, 3) and float(model._pc_for_alignloss.abs().max()) <= 3.0
+    model._pc_for_alignloss = torch.tensor(g["align_ref_cloud"])
+    t = lambda k, grad=True: torch.tensor(g[k], requires_grad=grad)
+    pts, poses, scal, stud = t("points_1"), t("poses"), t("scaling_factor"), t("pose_student")
+    outputs = model.replicate_outputs({"points_1": pts, "poses": poses, "scaling_factor": scal,
+                                       "focal_length": None, "pose_student": stud})
+    inputs = {"masks": t("masks", False)}
+    outputs = model.compute_projection(inputs, outputs, is_training=False)
+    loss = model.add_proj_loss(inputs, outputs, cfg.proj_weight)
+    loss.backward()
+    assert abs(float(loss) - float(g["align_loss_f64"])) < 1e-4 * float(g["align_loss_f64"])
+    assert relerr(stud.grad.numpy(), g["align_dstudent_f64"]) < 1e-4
+    assert relerr(poses.grad.numpy(), g["align_dposes_f64"]) < 2e-4
