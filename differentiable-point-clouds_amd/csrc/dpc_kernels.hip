@@ -1,11 +1,14 @@
 // dpc_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) and the
 // C ABI (include/dpc_hip.h) of the differentiable point-cloud projector.
 //
-// Fused hot path (power-of-two D in [64,256], K in {5,11,21}); grids are
-// [B,Dz,D,D], x fastest; V = bytes of one grid of one view:
+// Fused hot path (power-of-two D in [32,256], K in {5,11,21}); grids are
+// [B,Dz,D,D], x fastest; V = bytes of one grid of one view.  Planes that hold no
+// trilinear mass (one bit per plane, from the depth-cell histogram) are neither
+// written nor read anywhere on this path:
 //
 //   forward   k_zsort      WG/view: camera transform (quaternion or matrix) ->
-//                          tr_pc, LDS counting sort of the points by depth cell
+//                          tr_pc, LDS counting sort of the points by depth cell,
+//                          plane-occupancy bits
 //             k_splat_xy   WG/(view, plane, y-strip): zero an LDS tile, ds_add_f32
 //                          the plane's points, record one clip-gradient bit per
 //                          touched corner, clip, x-blur (halo from neighbour
@@ -18,13 +21,18 @@
 //   backward  k_zbwd       same walk: DRC VJP (suffix sum = saved total - fp64
 //                          prefix), scale/clip masks, dscale, z-FIR adjoint.
 //                                                               reads 1 V, writes 1 V
-//             k_gather_yx  WG/(view, 4 planes, y-strip): rows -> LDS (next plane
-//                          prefetched in registers), y-blur in place, sparse
+//             k_gather_yx  WG/(view, plane, y-strip): rows -> LDS, y-blur in place, sparse
 //                          x-blur + clip bits + trilinear gather at the plane's
 //                          points -> per-corner partial d(tr_pc).   reads ~1.2 V
 //             k_points_bwd thread/point: sum partials, camera-transform VJP,
 //                          block reduction of dq/dt/df into a [B,16] accumulator
-//             k_pose_finalize  quaternion normalisation Jacobian, dscale
+//                          (cleared by k_zbwd's first work-group per view)
+//             k_pose_finalize  quaternion normalisation Jacobian; dscale = fixed-order
+//                          sum of k_zbwd's per-work-group partials
+//
+// Outside the headline path, same ABI: k_sil_* (silhouette loss epilogue), k_gv_*
+// (exact Gaussian voxeliser, the reference's pc_fast:false splat), k_nn_distance
+// (nearest neighbour / Chamfer), k_scatter_vals / k_gather_vals (RGB channels).
 //
 // Generic path (any D, odd K <= 63, max-collapse, no blur, stage-level API):
 //   k_points_fwd (transform + 8 global_atomic_add_f32 into zero-filled G0),
