@@ -1631,6 +1631,9 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
   }
 }
 
+#ifndef DPC_ZBWD_PACKED
+#define DPC_ZBWD_PACKED 1   // 0: scalar per-ray arithmetic (A/B baseline)
+#endif
 // Backward, same walking direction as forward (so T_j and p_j are reproduced
 // bit for bit).  With gamma_i = dL/dp_i and a_i = gamma_i p_i:
 //   dL/dc_j = gamma_j Tq_j - (sum_{i>j} a_i) / (1 - c_j),   Tq_0 = e^eps, Tq_j = T_j,
@@ -1656,6 +1659,7 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
   const int col = (blockIdx.x * blockDim.x + threadIdx.x) * CX;
   const bool active = col < ncol;
   float dsacc[1] = {0.f};
+  dpc_v2f dsacc2 = dpc_v2f{0.f, 0.f};
   if (active) {
     const size_t base = (size_t)b * Dz * ncol + col;
     const int y = col / D, x0 = col - y * D;
@@ -1720,7 +1724,43 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
         const int j = t0 + u;
         if (j < T) {
           float dg2[CX], o[CX];
-          if (j < Dz) {
+          if (DPC_ZBWD_PACKED && CX == 2 && j < Dz) {
+            // two rays as one 2-vector: every add / mul / fma below is a v_pk_* instruction
+            const float psi = (float)j * rDz - 0.5f + P.camera_distance;
+            const dpc_v2f vv = dpc_v2f{buf[u][0], buf[u][1]};
+            const dpc_v2f sg = vv * dpc_v2f{s, s};
+            dpc_v2f g3 = vv;
+            if (has_s) g3 = dpc_v2f{clampf(sg[0], 0.f, 1.f), clampf(sg[1], 0.f, 1.f)};
+            const dpc_v2f cc = dpc_v2f{clampf(g3[0], eps, one_m), clampf(g3[1], eps, one_m)};
+            const dpc_v2f omc = dpc_v2f{1.f, 1.f} - cc;
+            const dpc_v2f Tq = (j == 0) ? dpc_v2f{e_eps, e_eps} : dpc_v2f{Tr[0], Tr[1]};
+            dpc_v2f gam = dpc_v2f{g[0], g[1]} + dpc_v2f{gd[0], gd[1]} * dpc_v2f{psi, psi};
+            if (dprobs) {
+              const float* dp = dprobs + ((size_t)j * B + b) * ncol + ocol;
+              gam += dpc_v2f{dp[0], dp[1]};
+            }
+            const dpc_v2f gT = gam * Tq;           // = a_j / c_j
+            const dpc_v2f aj = gT * cc;            // a_j = gamma_j p_j
+            tot[0] -= (double)aj[0];
+            tot[1] -= (double)aj[1];
+            const dpc_v2f rem = dpc_v2f{(float)tot[0], (float)tot[1]};
+            const dpc_v2f dc = gT - rem * dpc_v2f{dpc_rcp(omc[0]), dpc_rcp(omc[1])};
+            // eps <= G3 <= 1-eps  <=>  the clip was inactive
+            const dpc_v2f dg3 = dpc_v2f{(cc[0] == g3[0]) ? dc[0] : 0.f, (cc[1] == g3[1]) ? dc[1] : 0.f};
+            const dpc_v2f tn = dpc_v2f{Tr[0], Tr[1]} * omc;
+            Tr[0] = tn[0];
+            Tr[1] = tn[1];
+            if (has_s) {
+              const dpc_v2f sd = dpc_v2f{s, s} * dg3, vd = vv * dg3;
+              const bool m0 = (g3[0] == sg[0]), m1 = (g3[1] == sg[1]);   // 0 <= s G2 <= 1  <=>  clip inactive
+              dg2[0] = m0 ? sd[0] : 0.f;
+              dg2[1] = m1 ? sd[1] : 0.f;
+              dsacc2 += dpc_v2f{m0 ? vd[0] : 0.f, m1 ? vd[1] : 0.f};
+            } else {
+              dg2[0] = dg3[0];
+              dg2[1] = dg3[1];
+            }
+          } else if (j < Dz) {
             const float psi = (float)j * rDz - 0.5f + P.camera_distance;
 #pragma unroll
             for (int c = 0; c < CX; ++c) {
@@ -1768,6 +1808,7 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
         for (int c = 0; c < CX; ++c) bufA[u][c] = bufB[u][c];
     }
   }
+  dsacc[0] += dsacc2[0] + dsacc2[1];
   if (dsparts) {  // uniform across the grid: one partial per work-group, summed in fixed order by k_pose_finalize
     block_reduce_sum<1>(dsacc);
     if (threadIdx.x == 0) dsparts[(size_t)b * gridDim.x + blockIdx.x] = dsacc[0];
