@@ -2587,6 +2587,11 @@ int dpc_saved_layout(const DpcShape* shape, const DpcParams* params) {
   return splat_plan(*shape).ok ? 6 : 1;  // bit 0: grid_raw; bits 1+2: clip_mask + point_index
 }
 
+size_t dpc_point_index_ints(const DpcShape* shape) {
+  if (check_shape(shape, true) != DPC_OK || !splat_plan(*shape).ok) return 0;
+  return point_index_ints(*shape);
+}
+
 int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, int width) {
   if (!src || !dst) return DPC_E_NULL;
   if (n == 0 || (n % 4) != 0) return DPC_E_SHAPE;

@@ -151,7 +151,7 @@ class ProjectFused(torch.autograd.Function):
         lib.check(min(layout, 0), "dpc_saved_layout")
         grid_raw = new(B, Dz, D, D) if layout & 1 else None
         clip_mask = new(B, N, 4, dtype=torch.uint8) if layout & 2 else None
-        point_index = new(B * N + B * (Dz + 2) + B * 8, dtype=torch.int32) if layout & 4 else None
+        point_index = new(lib.dpc_point_index_ints(ctypes.byref(shape)), dtype=torch.int32) if layout & 4 else None
         grid_blur = new(B, Dz, D, D)
         drc = meta.collapse_mode == _capi.DPC_COLLAPSE_DRC
         logt = new(B, D, D, 2, dtype=torch.float64) if drc else None

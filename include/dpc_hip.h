@@ -85,11 +85,14 @@ int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, 
  * [B,N,4] bytes, one bit per touched trilinear corner (fused path: points are
  * bucketed by depth cell and splatted into per-plane LDS tiles, the raw grid
  * never reaches HBM); bit 2 (value 4) = point_index, int32
- * [B*N + B*(Dz+2) + B*8]: the points of each view sorted by depth cell, the
- * bucket starts, and 8 words of plane-occupancy bits per view, which the
- * backward re-uses (set together with bit 1).  Buffers
+ * [dpc_point_index_ints(shape)] = B*N + B*(Dz+2) + B*8: the points of each view
+ * sorted by depth cell, the bucket starts, and 8 words of plane-occupancy bits
+ * per view, which the backward re-uses (set together with bit 1).  Buffers
  * that are not used may be null.  <0 on error. */
 int dpc_saved_layout(const DpcShape* shape, const DpcParams* params);
+/* Number of int32 elements of the point_index buffer (0 when the shape does not
+ * use it). */
+size_t dpc_point_index_ints(const DpcShape* shape);
 
 /* Bytes of scratch `dpc_project_forward` (direction 0) / `dpc_project_backward`
  * (direction 1) need.  256-byte aligned device memory. */
