@@ -220,6 +220,33 @@ def test_hip_graph_replay_matches_eager():
         assert relerr(a.cpu().numpy(), b.cpu().numpy()) < 1e-4
 
 
+def test_integration_md_ctypes_stub_runs_standalone():
+    """The minimal ctypes binding printed in INTEGRATION.md (no dpc_amd import) drives the C ABI
+    and reproduces the product path."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(import ctypes, torch.*?)```", text, re.S).group(1)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        exec(compile(block, "INTEGRATION.md", "exec"), ns)
+        c = dpc_amd.synthetic.config_inputs(1, B=2)
+        cfg = dpc_amd.default_config(vox_size=c["D"], pc_gauss_kernel_size=c["K"])
+        kern = dpc_amd.smoothing_kernel(cfg, c["sigma"], device="cuda")
+        pc, pose, scale = (torch.tensor(c[k], device="cuda") for k in ("pc", "pose", "scale"))
+        taps = [k.reshape(-1).contiguous() for k in kern]
+        proj, depth, saved = ns["project_forward"](cfg, pc, pose, scale, taps)
+        torch.cuda.synchronize()
+    finally:
+        os.chdir(cwd)
+    ref = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale)
+    assert float((proj - ref["proj"]).abs().max()) < 2e-6
+    assert float((depth - ref["proj_depth"]).abs().max()) < 2e-5
+
+
 def test_d256_fused_path_against_numpy_oracle():
     """256^3 grid (BASELINE configs[4] resolution) at B=1: k_splat_xy / k_gather_yx with 32-row
     strips and 16-byte lanes, against the float64 NumPy oracle."""
