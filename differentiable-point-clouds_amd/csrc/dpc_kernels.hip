@@ -1552,17 +1552,32 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
     Qs[c] = 0.0;
   }
   const int T = Dz + h;
-  auto process = [&](const float (&buf)[G][CX], int t0) {
+  // One rolling group of G planes per lane: slot u holds plane t0+u; as soon as it has been consumed
+  // the load of plane t0+G+u is issued into the same registers, so G loads stay in flight per lane at
+  // all times with a single buffer (the register budget decides how many waves hide the latency).
+  static_assert(G <= 32, "one occupancy window per group of planes");
+  auto fetch = [&](unsigned win, int u, int t, float (&v)[CX]) {
+    // planes without mass were never written by the producer: substitute zeros (uniform branch)
+    if (!live || ((win >> u) & 1u)) {
+      zload<CX>(in + base, ncol, t, Dz, v);
+    } else {
+#pragma unroll
+      for (int c = 0; c < CX; ++c) v[c] = 0.f;
+    }
+  };
+  auto process = [&](float (&buf)[G][CX], int t0, unsigned win_next) {
 #pragma unroll
     for (int u = 0; u < G; ++u) {
       const int t = t0 + u;
-      if (t < T) {
-        float v[CX], g2[CX];
+      float v[CX];
 #pragma unroll
-        for (int c = 0; c < CX; ++c) {
-          const float r = (t < Dz) ? buf[u][c] : 0.f;
-          v[c] = clip_in ? clampf(r, 0.f, 1.f) : r;
-        }
+      for (int c = 0; c < CX; ++c) {
+        const float r = (t < Dz) ? buf[u][c] : 0.f;
+        v[c] = clip_in ? clampf(r, 0.f, 1.f) : r;
+      }
+      fetch(win_next, u, t + G, buf[u]);
+      if (t < T) {
+        float g2[CX];
         fir.push(v, g2, u);
         if (t >= h) {
           const int o = t - h;
@@ -1584,33 +1599,13 @@ k_zfwd(DpcParams P, const float* __restrict__ in, const float* __restrict__ taps
       }
     }
   };
-  // two groups of planes in flight, roles alternate (no register copies)
-  float bufA[G][CX], bufB[G][CX];
-  // planes without mass were never written by the producer: substitute zeros (uniform branch)
-  static_assert(G <= 32, "one occupancy window per group of planes");
-  auto fetch = [&](unsigned win, int u, int t, float (&v)[CX]) {
-    if (!live || ((win >> u) & 1u)) {
-      zload<CX>(in + base, ncol, t, Dz, v);
-    } else {
-#pragma unroll
-      for (int c = 0; c < CX; ++c) v[c] = 0.f;
-    }
-  };
+  float buf[G][CX];
   {
     const unsigned win = lm.window(0);
 #pragma unroll
-    for (int u = 0; u < G; ++u) fetch(win, u, u, bufA[u]);
+    for (int u = 0; u < G; ++u) fetch(win, u, u, buf[u]);
   }
-  for (int t0 = 0; t0 < T; t0 += G) {
-    const unsigned win = lm.window(t0 + G);
-#pragma unroll
-    for (int u = 0; u < G; ++u) fetch(win, u, t0 + G + u, bufB[u]);
-    process(bufA, t0);
-#pragma unroll
-    for (int u = 0; u < G; ++u)
-#pragma unroll
-      for (int c = 0; c < CX; ++c) bufA[u][c] = bufB[u][c];
-  }
+  for (int t0 = 0; t0 < T; t0 += G) process(buf, t0, lm.window(t0 + G));
   float pl[CX], pj[CX], dp[CX];
 #pragma unroll
   for (int c = 0; c < CX; ++c) {
@@ -1717,17 +1712,22 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
     fir.init(taps);
     const int T = Dz + h;
     // rem = total - sum_{i<=j} a_i, kept in float64 (no cancellation error)
-    auto process = [&](const float (&buf)[G][CX], int t0) {
+    // rolling group of G planes, refilled slot by slot (see k_zfwd)
+    auto process = [&](float (&buf)[G][CX], int t0) {
       const unsigned swin = lm.window(t0 - h);   // bit u: output plane t0 + u - h is read by k_gather_yx
 #pragma unroll
       for (int u = 0; u < G; ++u) {
         const int j = t0 + u;
+        float bv[CX];
+#pragma unroll
+        for (int c = 0; c < CX; ++c) bv[c] = buf[u][c];
+        zload<CX>(g2_in + base, ncol, j + G, Dz, buf[u]);
         if (j < T) {
           float dg2[CX], o[CX];
           if (DPC_ZBWD_PACKED && CX == 2 && j < Dz) {
             // two rays as one 2-vector: every add / mul / fma below is a v_pk_* instruction
             const float psi = (float)j * rDz - 0.5f + P.camera_distance;
-            const dpc_v2f vv = dpc_v2f{buf[u][0], buf[u][1]};
+            const dpc_v2f vv = dpc_v2f{bv[0], bv[1 % CX]};
             const dpc_v2f sg = vv * dpc_v2f{s, s};
             dpc_v2f g3 = vv;
             if (has_s) g3 = dpc_v2f{clampf(sg[0], 0.f, 1.f), clampf(sg[1], 0.f, 1.f)};
@@ -1764,7 +1764,7 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
             const float psi = (float)j * rDz - 0.5f + P.camera_distance;
 #pragma unroll
             for (int c = 0; c < CX; ++c) {
-              const float vv = buf[u][c];
+              const float vv = bv[c];
               const float sg = vv * s;
               const float g3 = has_s ? clampf(sg, 0.f, 1.f) : vv;
               const float cc = clampf(g3, eps, one_m);
@@ -1795,18 +1795,10 @@ k_zbwd(DpcParams P, const float* __restrict__ g2_in, const float* __restrict__ t
         }
       }
     };
-    float bufA[G][CX], bufB[G][CX];
+    float buf[G][CX];
 #pragma unroll
-    for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, u, Dz, bufA[u]);
-    for (int t0 = 0; t0 < T; t0 += G) {
-#pragma unroll
-      for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, t0 + G + u, Dz, bufB[u]);
-      process(bufA, t0);
-#pragma unroll
-      for (int u = 0; u < G; ++u)
-#pragma unroll
-        for (int c = 0; c < CX; ++c) bufA[u][c] = bufB[u][c];
-    }
+    for (int u = 0; u < G; ++u) zload<CX>(g2_in + base, ncol, u, Dz, buf[u]);
+    for (int t0 = 0; t0 < T; t0 += G) process(buf, t0);
   }
   dsacc[0] += dsacc2[0] + dsacc2[1];
   if (dsparts) {  // uniform across the grid: one partial per work-group, summed in fixed order by k_pose_finalize

@@ -13,6 +13,10 @@ import dpc_amd  # noqa: E402
 import bench  # noqa: E402
 
 cfg_id = int(os.environ.get("AB_CONFIG", "2"))
+if os.environ.get("AB_SHAPE"):      # e.g. AB_SHAPE=320,8000,64,21,3.0  (B,N,D,K,sigma) -> ad-hoc config 9
+    b_, n_, d_, k_, s_ = os.environ["AB_SHAPE"].split(",")
+    dpc_amd.synthetic.CONFIGS[9] = dict(B=int(b_), N=int(n_), D=int(d_), K=int(k_), sigma=float(s_))
+    cfg_id = 9
 B = os.environ.get("AB_BATCH")
 case = bench.build_case(cfg_id, int(B) if B else None, torch.device("cuda"))
 libs = [(os.path.basename(p), dpc_amd._capi.DpcLibrary(os.path.abspath(p))) for p in sys.argv[1:]]
