@@ -139,8 +139,12 @@ def get_library():
 
 
 def set_library(lib):
-    """Install a specific DpcLibrary (tests only: CPU emulation of the kernels).
-    Returns the previously active one (possibly None)."""
+    """Install a specific DpcLibrary; returns the previously active one (possibly None).
+    `None` (re-)selects the product library.  Anything that is not a device library -- i.e. the
+    CPU emulation build of the test tier -- is refused unless DPC_TEST_HOOKS=1 is set (the test
+    suite's conftest sets it), so that a product process cannot end up computing on the host."""
     global _ACTIVE
+    if lib is not None and getattr(lib, "host_memory", False) and os.environ.get("DPC_TEST_HOOKS") != "1":
+        raise DpcError("a host-memory (emulation) library can only be installed with DPC_TEST_HOOKS=1 (tests)")
     prev, _ACTIVE = _ACTIVE, lib
     return prev

@@ -9,6 +9,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+os.environ.setdefault("DPC_TEST_HOOKS", "1")         # allow installing the CPU emulation library (refused otherwise)
 os.environ.setdefault("DPC_POISON_BUFFERS", "1")   # NaN-fill kernel buffers: unwritten reads cannot hide
 
 

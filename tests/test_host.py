@@ -175,3 +175,10 @@ def test_reference_filter_shapes_pick_the_axis(emu):
     only_z = dpc_amd.smoothen_voxels3d(cfg, vox, [kz])
     ref = torch.nn.functional.conv3d(vox.permute(0, 4, 1, 2, 3), kz.reshape(1, 1, 3, 1, 1), padding=(1, 0, 0))
     assert float((only_z.permute(0, 4, 1, 2, 3) - ref).abs().max()) < 1e-6
+
+
+def test_emulation_library_is_refused_without_the_test_switch(monkeypatch, emu_library):
+    """A product process (no DPC_TEST_HOOKS) cannot install the host-memory emulation library."""
+    monkeypatch.delenv("DPC_TEST_HOOKS", raising=False)
+    with pytest.raises(_capi.DpcError, match="DPC_TEST_HOOKS"):
+        _capi.set_library(emu_library)
