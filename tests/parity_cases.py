@@ -299,3 +299,39 @@ def gauss_voxeliser_multitile_against_numpy_oracle(dev, B=1, N=100, G=70, sigma=
     assert maxabs(vox.detach().cpu().numpy(), ref) < 1e-5 * max(1.0, float(ref.max()))
     (vox * torch.tensor(w, device=dev)).sum().backward()
     assert relerr(t.grad.cpu().numpy(), dref) < TOL_GRAD
+
+
+def fused_edge_planes_against_numpy_oracle(dev):
+    """Plane-occupancy edge cases on the fused path (D = 32): a view whose points all fall outside the
+    cube (every plane empty), and a view with mass only in the first and the last depth cells."""
+    B, N, D, K, sigma = 2, 48, 32, 5, 1.0
+    rng = np.random.default_rng(3)
+    pc = np.zeros((B, N, 3), np.float32)
+    pc[0] = rng.uniform(1.5, 2.0, (N, 3))                                   # all outliers
+    pc[1, :, 1:] = rng.uniform(-0.2, 0.2, (N, 2))
+    pc[1, : N // 2, 0] = -0.5 + rng.uniform(1e-3, 5e-3, N // 2)             # depth cell 0
+    pc[1, N // 2:, 0] = 0.5 - rng.uniform(1e-3, 5e-3, N - N // 2)           # depth cell Dz-2 (planes Dz-2, Dz-1)
+    pose = np.tile(np.array([[1.0, 0.0, 0.0, 0.0]], np.float32), (B, 1))    # identity: depth = first component
+    scale = np.array([[0.9], [0.7]], np.float32)
+    inp = _nudge_off_cell_faces(dict(pc=pc, pose=pose, scale=scale), None, None, D, D)
+    cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K)
+    t = lambda a: torch.tensor(a, device=dev, requires_grad=True)
+    tpc, tpose, tscale = t(inp["pc"]), t(pose), t(scale)
+    kern = dpc_amd.smoothing_kernel(cfg, sigma, device=dev)
+    out = dpc_amd.pointcloud_project_fast(cfg, tpc, tpose, None, None, kern, scaling_factor=tscale)
+    w = rng.standard_normal(out["proj"].shape)
+    wd = 0.1 * rng.standard_normal(out["proj"].shape)
+    loss = (out["proj"] * torch.tensor(w, dtype=torch.float32, device=dev)).sum() + \
+           (out["proj_depth"] * torch.tensor(wd, dtype=torch.float32, device=dev)).sum()
+    grads = torch.autograd.grad(loss, [tpc, tpose, tscale])
+    f64 = lambda a: a.astype(np.float64)
+    taps = onp.smoothing_taps(D, -1, K, sigma)
+    fw = onp.project_forward(f64(inp["pc"]), f64(pose), None, f64(scale), None, taps, D, D)
+    bw = onp.project_backward(f64(inp["pc"]), f64(pose), None, f64(scale), None, taps, fw, dproj=w, dproj_depth=wd)
+    assert maxabs(out["proj"].detach().cpu().numpy(), fw["proj"]) < TOL_PROJ
+    assert maxabs(out["proj_depth"].detach().cpu().numpy(), fw["proj_depth"]) < TOL_DEPTH
+    empty_ray = 1.0 - (1.0 - 1e-5) ** D                                       # SURVEY.md A.2: every ray of view 0
+    assert abs(float(out["proj"][0].max()) - empty_ray) < 1e-6 and abs(float(out["proj"][0].min()) - empty_ray) < 1e-6
+    for name, g in zip(("dpc", "dpose", "dscale"), grads):
+        assert relerr(g.cpu().numpy().reshape(bw[name].shape), bw[name]) < TOL_GRAD, name
+    assert float(grads[0][0].abs().max()) == 0.0                              # outliers get no gradient

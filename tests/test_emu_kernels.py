@@ -101,3 +101,7 @@ def test_emu_slow_projector(emu):
 def test_emu_gauss_voxeliser_multitile(emu):
     parity_cases.gauss_voxeliser_multitile_against_numpy_oracle("cpu", N=70, G=66)
 
+
+def test_emu_fused_edge_planes(emu):
+    parity_cases.fused_edge_planes_against_numpy_oracle("cpu")
+

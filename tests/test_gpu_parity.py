@@ -247,6 +247,10 @@ def test_integration_md_ctypes_stub_runs_standalone():
     assert float((depth - ref["proj_depth"]).abs().max()) < 2e-5
 
 
+def test_fused_edge_planes():
+    parity_cases.fused_edge_planes_against_numpy_oracle("cuda")
+
+
 def test_d256_fused_path_against_numpy_oracle():
     """256^3 grid (BASELINE configs[4] resolution) at B=1: k_splat_xy / k_gather_yx with 32-row
     strips and 16-byte lanes, against the float64 NumPy oracle."""
