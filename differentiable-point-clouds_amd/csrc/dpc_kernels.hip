@@ -360,16 +360,21 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   const float* zin;
   int clip_in;
   unsigned* live = nullptr;
+  bool save_xy = false;
   if (plan.ok) {
     // 1+2 fused front end: transform + z-bucket (one WG per view) -> per-plane LDS splat + clip + x,y blur
     int* order = (int*)point_index;                  // [B,N]   points sorted by depth cell
     int* zstart = order + (size_t)S.B * S.N;         // [B,Dz+2] bucket starts
     live = (unsigned*)(zstart + (size_t)S.B * (S.Dz + 2));   // [B,8] plane-occupancy bits
-    // planes without mass are skipped end to end when the consumer is the mask-aware k_zfwd
-    rc = launch_splat_xy(st, S, P, plan, pc, pose, trans, focal, tr_pc, order, zstart, taps_x, taps_y, tmp,
+    // With the fused z pass as consumer, planes without mass are skipped end to end, and the xy-blurred
+    // grid is what gets SAVED (in the grid_blur buffer): k_zfwd then only reads -- storing G2 was its
+    // bottleneck -- and k_zbwd re-applies the z-FIR to the saved planes (DPC_SAVE_XY).
+    save_xy = save_xy_mode(S, drc);
+    float* xy_out = save_xy ? grid_blur : tmp;
+    rc = launch_splat_xy(st, S, P, plan, pc, pose, trans, focal, tr_pc, order, zstart, taps_x, taps_y, xy_out,
                          clip_mask, live, drc && z_fixed(S.Kz));
     if (rc) return rc;
-    zin = tmp;
+    zin = xy_out;
     clip_in = 0;
   } else {
     // 1. zero G0, transform + scatter (global float atomics)
@@ -393,8 +398,8 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   }
   // 3. z blur fused with the ray collapse
   if (drc && z_fixed(S.Kz))
-    return launch_zfwd(st, S, P, zin, taps_z, S.Kz, scale, grid_blur, nullptr, proj, proj_depth, ray_sums,
-                       clip_in, 1, live);
+    return launch_zfwd(st, S, P, zin, taps_z, S.Kz, scale, save_xy ? nullptr : grid_blur, nullptr, proj, proj_depth,
+                       ray_sums, clip_in, 1, live);
   // generic tap count or max-collapse: materialise G2, then collapse separately
   if (S.Kz > 0) {
     if (clip_in) return DPC_E_MODE;  // z-only blur of the raw grid is not a reference configuration
@@ -459,10 +464,12 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   // 1. collapse VJP (+ z-FIR adjoint) -> tA
   const bool yx = use_cmask && plan.gSH > 0;   // consumer of tA is k_gather_yx (reads occupied planes only)
   if (zfused) {
-    const unsigned* live =
-        yx ? (const unsigned*)(point_index + (size_t)S.B * S.N + (size_t)S.B * (S.Dz + 2)) : nullptr;
+    const unsigned* live_all =
+        use_cmask ? (const unsigned*)(point_index + (size_t)S.B * S.N + (size_t)S.B * (S.Dz + 2)) : nullptr;
+    const unsigned* live = yx ? live_all : nullptr;
+    // fused forward (plan.ok): grid_blur holds the xy-blurred grid, see dpc_project_forward
     rc = launch_zbwd(st, S, P, grid_blur, taps_z, S.Kz, scale, ray_sums, dproj, dproj_depth, nullptr, tA,
-                     ds_acc, 1, live, scale ? dsparts : nullptr, accum);
+                     ds_acc, 1, live, scale ? dsparts : nullptr, accum, live_all, use_cmask && save_xy_mode(S, drc));
     if (rc) return rc;
   } else {
     float* first = (S.Kz > 0) ? tB : tA;
