@@ -64,7 +64,8 @@ def kernel_algorithmic_bytes(label, case):
     zero-fill writes one (1 V); point kernels move O(N) bytes + their atomics."""
     V = 4 * case["D"] ** 3
     B, N = case["B"], case["N"]
-    dense = {"zfwd": 2 * V, "zbwd": 2 * V, "blur_plane": 2 * V, "blur_xy": 2 * V, "blur_z": 2 * V, "memset_grid": V,
+    # fused path with K <= 11: k_zfwd only reads (the xy-blurred grid is what is saved), k_zbwd reads it + writes one
+    dense = {"zfwd": (V if case["K"] <= 11 else 2 * V), "zbwd": 2 * V, "blur_plane": 2 * V, "blur_xy": 2 * V, "blur_z": 2 * V, "memset_grid": V,
              "splat_xy": V, "gather_yx": V}
     if label in dense:
         return B * dense[label]

@@ -107,7 +107,9 @@ size_t dpc_workspace_bytes(const DpcShape* shape, int direction);
  *   -> drc_depth_projection (drc.py:146-153) -> flips (:270,273).
  * Saved for backward (caller-owned): tr_pc [B,N,3], grid_raw [B,Dz,D,D]
  * (pre-clip scatter) OR clip_mask [B,N,4] bytes + point_index (see dpc_saved_layout),
- * grid_blur [B,Dz,D,D] (post-blur, pre-scale),
+ * grid_blur [B,Dz,D,D] (opaque to the caller: the post-blur, pre-scale grid G2 --
+ * or, on the fused path with at most 11 z taps, the xy-blurred grid with its
+ * empty planes left unwritten; the backward re-applies the z blur to it),
  * ray_sums [B,D,D,2] float64 (per ray, grid-row order: sum_{j<Dz} p_j and
  * sum_{j<=Dz} p_j psi_j of the event probabilities, needed by the backward).
  * trans/scale/focal/taps/proj_depth nullable.  proj, proj_depth are H-flipped. */
