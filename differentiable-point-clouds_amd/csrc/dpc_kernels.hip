@@ -15,10 +15,13 @@
 //                          lanes, ds_bpermute), y-blur (rotating register FIR)
 //                          -> xy-blurred plane.                      writes 1 V
 //             k_zfwd       thread = CX adjacent rays, streams z once: register
-//                          z-FIR, writes G2 (saved), scale/clip, DRC collapse as a
-//                          running transmittance product (no log/exp), silhouette
-//                          + depth + two fp64 sums per ray.     reads 1 V, writes 1 V
-//   backward  k_zbwd       same walk: DRC VJP (suffix sum = saved total - fp64
+//                          z-FIR, scale/clip, DRC collapse as a running
+//                          transmittance product (no log/exp), silhouette + depth
+//                          + two fp64 sums per ray.  With <= 11 z taps it only
+//                          READS: the xy-blurred grid itself is what is saved for
+//                          backward (storing G2 was 41 % of its time).  reads 1 V
+//   backward  k_zbwd       same walk: (re-applies the z-FIR to the saved xy grid,
+//                          bit for bit,) DRC VJP (suffix sum = saved total - fp64
 //                          prefix), scale/clip masks, dscale, z-FIR adjoint.
 //                                                               reads 1 V, writes 1 V
 //             k_gather_yx  WG/(view, plane, y-strip): rows -> LDS, y-blur in place, sparse
