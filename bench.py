@@ -1,30 +1,40 @@
 #!/usr/bin/env python3
 """Headline benchmark: projected views/sec, forward + backward, of
-pointcloud_project_fast on synthetic point clouds (BASELINE.json configs[1]:
-8000 pts -> 128^3 -> 128^2, batch 32 per GPU, sigma 1.6, K = 11).
+pointcloud_project_fast on synthetic point clouds.
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py                                   # 1 GPU, BASELINE.json configs[1]
+    python bench.py --gpus 8 --steps 20 --warmup 5    # spawns 8 ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...   # or under an external launcher
 
-One "step" = one fwd+bwd pass of the projector over one batch of B views per
-GPU (grads w.r.t. point_cloud, transform, scaling_factor given
-dproj = (proj - gt)/B, the reference's L2 loss gradient, model_pc.py:414-415).
-The path shards over instances with no data-path collective (weak scaling,
-B views per GPU); ranks only meet at the timing barriers.
+--config  1  configs[0]   1000 pts ->  64^3, K=11, 4 views            (launch-bound plumbing case)
+          2  configs[1]   8000 pts -> 128^3, K=11, 32 views per GPU   (DEFAULT, the headline)
+          3  configs[2]   full chair_unsupervised training step: encoder + decoder + pose candidates (stock
+                          PyTorch) -> HIP projector (16 models x 5 views x 4 candidates = 320 views of
+                          8000*keep pts -> 64^3, K=21) -> HIP silhouette-loss epilogue -> backward -> Adam.
+                          With --gpus N > 1 this is configs[3]: DDP over models, RCCL all-reduce of the
+                          parameter gradients.  --projector-only times just the projector at that shape.
+          5  configs[4]   16000 pts -> 256^3, K=11, 8 views            (HBM stress)
 
-Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline     dominant kernel: algorithmic bytes per launch / its mean launch
-               duration (HIP events on the launch stream, dpc_profile_*),
-               against the 8 TB/s HBM3E peak; plus step_* = the whole fwd+bwd
-               step against SURVEY.md 8(d)'s 8 V + P bytes per view
-  cpu_baseline the oracle's op-for-op torch-CPU restatement of the reference
-               graph (oracle/reference_cpu.py, kind "port"), timed on a bounded
-               sample on this host's cores (rank 0, N = 1 only)
+One "step" = one fwd+bwd pass over one batch of B views per GPU (grads w.r.t. point_cloud, transform,
+scaling_factor given dproj = (proj - gt)/B, the reference's L2 loss gradient, model_pc.py:414-415; config 3:
+one optimiser step).  The projector shards over instances with no data-path collective (weak scaling, B views
+per GPU); ranks only meet at the timing barriers (config 3: plus DDP's gradient all-reduce).
+
+Rank 0 prints ONE JSON line.  `value` comes from EXACTLY --steps steps after --warmup untimed ones, bracketed
+by barrier + torch.cuda.synchronize() on both sides, max over ranks.  Besides the contract keys:
+  timing       --repeats further blocks of --steps steps, each timed with HIP events: median / p10 / p90
+  roofline     dominant projector kernel: algorithmic bytes per launch / its mean launch duration (HIP events
+               on the launch stream, dpc_profile_*), against the 8 TB/s HBM3E peak; step_* = the projector's
+               whole fwd+bwd against SURVEY.md 8(d)'s 8 V + P bytes per view
+  cpu_baseline oracle/reference_cpu.py (op-for-op torch-CPU restatement of the reference graph, kind "port")
+               on a bounded sample on this host's cores (rank 0, N = 1 only)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,9 +46,15 @@ sys.path.insert(0, ROOT)
 import dpc_amd  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+DRY_RUN = os.environ.get("DPC_BENCH_DRY_RUN") == "1"   # tests only: CPU emulation library + gloo, not a measurement
+
+# projector shape of the training step (experiments/chair_unsupervised/config.yaml:7-14)
+dpc_amd.synthetic.CONFIGS.setdefault(3, dict(B=320, N=8000, D=64, K=21, sigma=3.0))
 
 
-def build_case(cfg_id, B, device, seed_offset=0, kind="shell"):
+def build_case(cfg_id, B, device, seed_offset=0, kind="shell", N=None):
+    if N is not None:
+        dpc_amd.synthetic.CONFIGS[cfg_id] = dict(dpc_amd.synthetic.CONFIGS[cfg_id], N=int(N))
     c = dpc_amd.synthetic.config_inputs(cfg_id, B=B, kind=kind, seed_offset=seed_offset)
     cfg = dpc_amd.default_config(vox_size=c["D"], pc_gauss_kernel_size=c["K"])
     t = lambda a: torch.tensor(a, device=device, requires_grad=True)
@@ -58,15 +74,38 @@ def step(case):
     return torch.autograd.grad(proj, [case["pc"], case["pose"], case["scale"]], dproj)
 
 
-def kernel_algorithmic_bytes(label, case):
+def build_train_case(args, device, rank, world):
+    """configs[2]/[3]: the full training step of examples/chair_unsupervised."""
+    sys.path.insert(0, os.path.join(ROOT, "examples", "chair_unsupervised"))
+    import train_step as ts
+    from nets import Im2PointCloud
+    models = args.batch or 16
+    cfg = ts.make_cfg(batch_size=models, pc_point_dropout=args.keep_prob, pc_point_dropout_scheduled=False)
+    torch.manual_seed(0)
+    net = Im2PointCloud(cfg, 128).to(device)
+    model = net
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[device.index], bucket_cap_mb=64,
+                                                          gradient_as_bucket_view=True)
+    projector = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device=device)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    inputs = ts.synthetic_batch(cfg, device, 128, seed=rank)
+    views = cfg.batch_size * cfg.step_size * cfg.pose_predict_num_candidates
+    case = dict(B=views, N=int(cfg.pc_num_points * args.keep_prob), D=cfg.vox_size, K=cfg.pc_gauss_kernel_size,
+                sigma=cfg.pc_relative_sigma, models=models, params=sum(p.numel() for p in net.parameters()),
+                run=lambda: ts.train_step(model, projector, inputs, opt, world))
+    return case
+
+
+def kernel_algorithmic_bytes(label, case, save_xy):
     """Compulsory HBM bytes of ONE launch over the batch (DESIGN.md 'Kernels'):
     every dense kernel reads one grid and writes one grid (2 V per view); the
     zero-fill writes one (1 V); point kernels move O(N) bytes + their atomics."""
     V = 4 * case["D"] ** 3
     B, N = case["B"], case["N"]
-    # fused path with K <= 11: k_zfwd only reads (the xy-blurred grid is what is saved), k_zbwd reads it + writes one
-    dense = {"zfwd": (V if case["K"] <= 11 else 2 * V), "zbwd": 2 * V, "blur_plane": 2 * V, "blur_xy": 2 * V, "blur_z": 2 * V, "memset_grid": V,
-             "splat_xy": V, "gather_yx": V}
+    # save_xy (fused path): k_zfwd only reads (the xy-blurred grid is what is saved), k_zbwd reads it + writes one
+    dense = {"zfwd": (V if save_xy else 2 * V), "zbwd": 2 * V, "blur_plane": 2 * V, "blur_xy": 2 * V,
+             "blur_z": 2 * V, "memset_grid": V, "splat_xy": V, "gather_yx": V}
     if label in dense:
         return B * dense[label]
     if label == "points_fwd":
@@ -78,8 +117,20 @@ def kernel_algorithmic_bytes(label, case):
     return 0
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
+
+
 def cpu_baseline(cfg_id, seconds_budget=20.0):
-    """oracle/reference_cpu.py on a bounded sample of the same workload."""
+    """oracle/reference_cpu.py on a bounded sample (B = 2 views) of the same workload: 1 thread, every host
+    CPU, and the best of a few thread counts (median of >= 3 runs each; `value` is the best one)."""
     from oracle import reference_cpu as rcpu
     c = dpc_amd.synthetic.config_inputs(cfg_id, B=2)
     cfg = rcpu.Cfg(vox_size=c["D"], pc_gauss_kernel_size=c["K"])
@@ -94,43 +145,54 @@ def cpu_baseline(cfg_id, seconds_budget=20.0):
         dproj = (out["proj"].detach() - gt) / 2
         torch.autograd.grad(out["proj"], [pc, pose, scale], dproj)
 
-    one()                                   # warm-up (allocator)
-    # torch's default thread count (= all logical CPUs) oversubscribes badly on this workload
-    # (measured on the 256-thread GPU box: 128 threads 5 views/s, 16 threads 55 views/s), so pick
-    # the best of a few counts with one run each, then time the sample with that count
-    best = None
-    for thr in sorted({1, 4, 8, 16, 32, min(64, os.cpu_count() or 1)}):
-        if thr > (os.cpu_count() or 1):
-            continue
+    def med(thr, runs, budget, cap=8.0):
+        """median of >= `runs` runs (more while `budget` seconds last); a thread count whose single run takes
+        longer than `cap` seconds (all 256 threads of the GPU box: ~20 s per run) is timed once"""
         torch.set_num_threads(thr)
-        one()
-        t0 = time.perf_counter()
-        one()
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
-            best = (dt, thr)
-    torch.set_num_threads(best[1])
-    times = []
-    t_start = time.perf_counter()
-    while len(times) < 5 or (time.perf_counter() - t_start < seconds_budget and len(times) < 200):
-        t0 = time.perf_counter()
-        one()
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    cpu_model = ""
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    cpu_model = line.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
-    return {"value": 2.0 / med, "unit": "views/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "B=2 of the %d-view batch (same N=%d, %d^3, K=%d), fwd+bwd, median of %d runs at the best of {1,4,8,16,32,64} torch threads, "
-                      "oracle/reference_cpu.py (torch-CPU op-for-op restatement of the TF1 graph)"
-                      % (dpc_amd.synthetic.CONFIGS[cfg_id]["B"], c["N"], c["D"], c["K"], len(times)),
-            "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
+        ts, t_start = [], time.perf_counter()
+        while len(ts) < runs or (time.perf_counter() - t_start < budget and len(ts) < 200):
+            t0 = time.perf_counter()
+            one()
+            ts.append(time.perf_counter() - t0)
+            if ts[-1] > cap:
+                break
+        return float(np.median(ts)), len(ts)
+
+    one()                                       # warm-up (allocator, lazy initialisation)
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    # torch's default thread count (every logical CPU) oversubscribes badly on this workload (256-thread GPU
+    # box: 128 threads 5 views/s, 16 threads 55 views/s): probe a ladder, >= 3 runs each, keep the best
+    ladder = sorted({t for t in (1, 4, 8, 16, 32, 64, ncpu) if t <= ncpu})
+    probe = {}
+    for thr in ladder:
+        probe[thr] = med(thr, 3, 0.0)[0]
+    best_thr = min(probe, key=probe.get)
+    best, nruns = med(best_thr, 5, seconds_budget)
+    torch.set_num_threads(default_threads)
+    return {"value": 2.0 / best, "unit": "views/s", "cores": int(best_thr), "kind": "port",
+            "sample": "B=2 views of the workload's shape (N=%d, %d^3, K=%d), fwd+bwd, median of %d runs at the best "
+                      "of %s torch threads (>= 3 runs each), oracle/reference_cpu.py (torch-CPU op-for-op "
+                      "restatement of the TF1 graph)" % (c["N"], c["D"], c["K"], nruns, ladder),
+            "value_1_thread": 2.0 / probe[1], "value_all_cores": 2.0 / probe[ncpu],
+            "views_per_s_by_threads": {str(k): round(2.0 / v, 2) for k, v in sorted(probe.items())},
+            "host_cpus": ncpu, "cpu_model": _cpu_model()}
+
+
+def self_launch(ngpus, argv):
+    """`python bench.py --gpus N` outside a launcher: start N ranks through torch.distributed.run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def pctl(a, q):
+    return float(np.percentile(np.asarray(a, dtype=np.float64), q))
 
 
 def main():
@@ -138,29 +200,52 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 5])
-    ap.add_argument("--batch", type=int, default=None, help="views per GPU (default: the config's)")
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 5])
+    ap.add_argument("--batch", type=int, default=None,
+                    help="views per GPU (config 3: models per GPU; default: the config's)")
     ap.add_argument("--points", default="shell", choices=["shell", "ball"],
                     help="synthetic cloud: noisy sphere shell (surface-like, default) or uniform ball (SURVEY.md 8(d))")
+    ap.add_argument("--num-points", type=int, default=None, help="override N (projector-only workloads)")
+    ap.add_argument("--projector-only", action="store_true", help="config 3: time the projector alone at the training shape")
+    ap.add_argument("--keep-prob", type=float, default=1.0, help="config 3: point dropout keep probability (N = 8000 * keep)")
     ap.add_argument("--graph", action="store_true",
                     help="capture one fwd+bwd step in a HIP graph and replay it (launch-bound small configs)")
+    ap.add_argument("--repeats", type=int, default=None,
+                    help="extra HIP-event-timed blocks of --steps steps for median/p10/p90 (default: >= 10, >= 1 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
     dd = dpc_amd.distributed
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank, _, world = dd.env_world()
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (the projector has no CPU fallback)")
-    rank, world, device = dd.init("nccl")
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if DRY_RUN:
+        # launch / rendezvous / reporting logic on a GPU-less host (tests/test_bench_launch.py): the kernels'
+        # CPU emulation build, gloo, toy sizes.  Refused unless the test hooks are on; never a measurement.
+        emu = dpc_amd._capi.DpcLibrary(os.path.join(ROOT, "tests", "hipemu", "libdpc_emu.so"), host_memory=True)
+        dpc_amd._capi.set_library(emu)
+        torch.set_num_threads(1)
+        rank, world, device = dd.init("gloo", device=torch.device("cpu"))
+        dpc_amd.synthetic.CONFIGS[args.config] = dict(B=2, N=150, D=32, K=5, sigma=0.9)
+        args.steps, args.warmup, args.repeats, args.no_cpu_baseline = min(args.steps, 2), min(args.warmup, 1), 0, True
+        args.projector_only = True
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm GPU (the projector has no CPU fallback)")
+        rank, world, device = dd.init("nccl")
 
     lib = dpc_amd.get_library()
-    case = build_case(args.config, args.batch, device, seed_offset=1000 * rank, kind=args.points)
-
-    run = lambda: step(case)
-    if args.graph:
+    train = args.config == 3 and not args.projector_only
+    if train:
+        case = build_train_case(args, device, rank, world)
+        run = case["run"]
+    else:
+        case = build_case(args.config, args.batch, device, seed_offset=1000 * rank, kind=args.points, N=args.num_points)
+        run = lambda: step(case)
+    if args.graph and not train:
         # the library only enqueues on the stream it is handed, so a whole step (forward, loss
         # gradient, backward) records into one hipGraph; replay costs one launch on the host
         side = torch.cuda.Stream()
@@ -181,15 +266,34 @@ def main():
         run()
     dd.barrier(device)
     elapsed = dd.max_over_ranks(time.perf_counter() - t0, device)
+    ms_step = elapsed / args.steps * 1e3
+
+    # ---- spread: further blocks of `steps` steps, HIP events on the launch stream, every rank in step ----
+    repeats = args.repeats
+    if repeats is None:
+        repeats = int(min(200, max(10, np.ceil(1000.0 / max(ms_step * args.steps, 1e-3)))))
+    blocks = []
+    for _ in range(repeats):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            run()
+        e1.record()
+        e1.synchronize()
+        blocks.append(e0.elapsed_time(e1) / args.steps)
+    if world > 1:
+        dd.barrier(device)
 
     # ---- per-kernel durations (HIP events on the launch stream), rank 0 ----------
     roof = None
-    if rank == 0:
-        psteps = max(3, min(args.steps, 20))
-        lib.profile(True)
+    psteps = max(3, min(args.steps, 20))
+    if not DRY_RUN:                         # every rank steps (DDP's all-reduce needs them all); rank 0 records
+        if rank == 0:
+            lib.profile(True)
         for _ in range(psteps):
-            step(case)
+            case["run"]() if train else step(case)
         torch.cuda.synchronize()
+    if rank == 0 and not DRY_RUN:
         recs = lib.profile_records()
         lib.profile(False)
         agg = {}
@@ -200,45 +304,66 @@ def main():
         per_step = {k: v[1] / psteps for k, v in agg.items()}
         dom = max(agg, key=lambda k: agg[k][1])
         dom_ms = agg[dom][1] / agg[dom][0]
-        alg = kernel_algorithmic_bytes(dom, case)
+        save_xy = lib.saves_xy(case["B"], case["N"], case["D"], case["K"])
+        alg = kernel_algorithmic_bytes(dom, case, save_xy)
         traffic, tsrc = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                ent = tj.get("config%d" % args.config, {}).get(dom)
-                if ent is not None and case["B"] == tj.get("config%d" % args.config, {}).get("B"):
-                    traffic, tsrc = ent, "profiles/traffic.json (rocprofv3 --pmc passes, see profiles/README.md)"
+                ent = json.load(open(tpath)).get("config%d" % args.config, {})
+                if ent.get(dom) is not None and case["B"] == ent.get("B") and case["N"] == ent.get("N", case["N"]):
+                    traffic, tsrc = ent[dom], "profiles/traffic.json (rocprofv3 --pmc passes, see profiles/README.md)"
             except (ValueError, OSError):
                 pass
         step_bytes = dpc_amd.synthetic.algorithmic_bytes_per_view(case["N"], case["D"], case["D"]) * case["B"]
-        ms_step = elapsed / args.steps * 1e3
+        proj_ms = sum(per_step.values()) if train else ms_step     # config 3: the projector's share of the step
         roof = {"bound": "hbm", "kernel": dom, "achieved": alg / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": alg / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": tsrc, "kernel_ms": dom_ms, "kernel_alg_bytes": alg,
                 "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items())},
-                "step_alg_bytes": step_bytes, "step_achieved": step_bytes / (ms_step * 1e-3) / 1e9,
-                "step_frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                "step_alg_bytes": step_bytes, "step_ms": proj_ms,
+                "step_scope": ("library kernels only (sum of their HIP-event durations inside the training step)"
+                               if train else "whole timed step"),
+                "step_achieved": step_bytes / (proj_ms * 1e-3) / 1e9,
+                "step_frac": step_bytes / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     if rank == 0:
         views = world * case["B"] * args.steps
+        cfg_idx = {1: 0, 2: 1, 3: 2 if world == 1 else 3, 5: 4}[args.config]
+        if train:
+            workload = ("BASELINE.json configs[%d]: chair_unsupervised training step (encoder+decoder+pose nets, stock "
+                        "PyTorch; HIP projector + silhouette-loss epilogue; Adam), %d models x 5 views x 4 pose "
+                        "candidates = %d views per GPU of N=%d pts -> %d^3, K=%d, sigma=%.1f, %.1f M parameters%s"
+                        % (cfg_idx, case["models"], case["B"], case["N"], case["D"], case["K"], case["sigma"],
+                           case["params"] / 1e6, ", DDP (RCCL all-reduce)" if world > 1 else ""))
+        else:
+            workload = ("BASELINE.json configs[%d]%s: pointcloud_project_fast fwd+bwd, N=%d, grid %d^3, K=%d, sigma=%.1f, "
+                        "batch %d views per GPU, %s point clouds, dproj=(proj-gt)/B"
+                        % (cfg_idx, " (projector only)" if args.config == 3 else "", case["N"], case["D"], case["K"],
+                           case["sigma"], case["B"], args.points))
         line = {
             "metric": "projected views/sec (fwd+bwd), %d pts->%d^3->%d^2 at bs=%d per GPU"
                       % (case["N"], case["D"], case["D"], case["B"]),
             "value": views / elapsed, "unit": "views/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[%d]: pointcloud_project_fast fwd+bwd, N=%d, "
-                                   "grid %d^3, K=%d, sigma=%.1f, batch %d views per GPU, %s point clouds, "
-                                   "dproj=(proj-gt)/B" % ({1: 0, 2: 1, 5: 4}[args.config], case["N"], case["D"],
-                                                         case["K"], case["sigma"], case["B"], args.points),
-                       "global_batch": world * case["B"], "K": case["K"], "hip_graph": bool(args.graph), "parallelism": "views sharded x%d, "
-                       "no data-path collective" % world},
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not DRY_RUN else "dry run on the CPU emulation library: NOT a measurement",
+            "config": {"workload": workload, "global_batch": world * case["B"], "K": case["K"],
+                       "hip_graph": bool(args.graph), "training_step": bool(train),
+                       "parallelism": ("models sharded x%d (DDP), gradient all-reduce over RCCL" % world) if train else
+                                      ("views sharded x%d, no data-path collective" % world)},
+            "timing": None if not blocks else {
+                "repeats": len(blocks), "steps_per_block": args.steps, "clock": "HIP events, rank 0",
+                "ms_per_step_median": pctl(blocks, 50), "ms_per_step_p10": pctl(blocks, 10),
+                "ms_per_step_p90": pctl(blocks, 90),
+                "value_median": world * case["B"] / (pctl(blocks, 50) * 1e-3)},
             "roofline": roof,
         }
+        if train:
+            line["steps_per_s"] = args.steps / elapsed
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     dd.finalize()
 
 

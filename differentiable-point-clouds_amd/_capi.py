@@ -113,6 +113,13 @@ class DpcLibrary(object):
             out.append((name.value.decode(), float(ms.value)))
         return out
 
+    def saves_xy(self, B, N, D, K, Dz=None):
+        """True when the fused path keeps the xy-blurred grid (not G2) for backward at this shape
+        (bit 3 of dpc_saved_layout): k_zfwd is then read-only, which bench.py's byte model needs to know."""
+        shape = DpcShape(int(B), int(N), int(Dz or D), int(D), int(K), int(K), int(K))
+        params = DpcParams(2.0, 1.875, 1e-5, 10.0, 1, DPC_COLLAPSE_DRC, 0)
+        return bool(self.dpc_saved_layout(ctypes.byref(shape), ctypes.byref(params)) & 8)
+
     @staticmethod
     def check(rc, what):
         if rc == 0:

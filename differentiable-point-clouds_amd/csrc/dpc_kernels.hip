@@ -147,7 +147,9 @@ int dpc_profile_enable(int on) {
 
 int dpc_saved_layout(const DpcShape* shape, const DpcParams* params) {
   if (check_shape(shape, true) != DPC_OK || !params) return DPC_E_SHAPE;
-  return splat_plan(*shape).ok ? 6 : 1;  // bit 0: grid_raw; bits 1+2: clip_mask + point_index
+  if (!splat_plan(*shape).ok) return 1;   // bit 0: grid_raw
+  // bits 1+2: clip_mask + point_index; bit 3 (informational): grid_blur holds the xy-blurred grid, not G2
+  return 6 | (save_xy_mode(*shape, params->collapse_mode == DPC_COLLAPSE_DRC) ? 8 : 0);
 }
 
 size_t dpc_point_index_ints(const DpcShape* shape) {

@@ -59,7 +59,10 @@ def max_over_ranks(value, device=None):
     """MAX all-reduce of a python float (the step time of the slowest rank)."""
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device or torch.device("cpu"))
+    if device is None:      # the RCCL ("nccl") backend only reduces device tensors
+        on_gpu = dist.get_backend() == "nccl"
+        device = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

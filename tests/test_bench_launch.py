@@ -1,0 +1,56 @@
+"""bench.py's launch / rendezvous / reporting logic on a GPU-less host.
+
+`python bench.py --gpus 2 --steps 20 --warmup 5` is what the driver types; without WORLD_SIZE in the
+environment bench.py must start the two ranks itself (torch.distributed.run), and rank 0 must print ONE
+JSON line with n_gpus = 2.  Here the ranks run the kernels' CPU emulation build under gloo at toy sizes
+(DPC_BENCH_DRY_RUN=1, refused without the test hooks): the numbers mean nothing, the plumbing is what is
+checked.  The same command on a GPU box runs the real thing."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, extra_env=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR",
+                                                            "MASTER_PORT")}
+    env.update(DPC_BENCH_DRY_RUN="1", DPC_TEST_HOOKS="1", OMP_NUM_THREADS="1")
+    env.pop("DPC_POISON_BUFFERS", None)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, cwd=ROOT,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_gpus_2_self_launches_and_prints_one_line(emu_library):
+    r = _run(["--gpus", "2", "--steps", "20", "--warmup", "5"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["unit"] == "views/s"
+    assert j["config"]["global_batch"] == 2 * 2
+    assert j["value"] > 0 and j["ms_per_step"] > 0 and "NOT a measurement" in j["data"]
+    assert "cpu_baseline" not in j                   # rank 0 at N = 1 only
+
+
+def test_gpus_1_runs_in_process(emu_library):
+    r = _run(["--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1
+
+
+def test_world_size_mismatch_is_an_error(emu_library):
+    r = _run(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_dry_run_is_refused_without_test_hooks(emu_library):
+    r = _run(["--steps", "1", "--warmup", "0"], {"DPC_TEST_HOOKS": "0"})
+    assert r.returncode != 0 and "DPC_TEST_HOOKS" in r.stderr
