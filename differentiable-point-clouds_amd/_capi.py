@@ -36,7 +36,7 @@ class DpcParams(ctypes.Structure):
     _fields_ = [("camera_distance", ctypes.c_float), ("focal_length", ctypes.c_float),
                 ("eps", ctypes.c_float), ("max_depth", ctypes.c_float),
                 ("pose_is_quaternion", ctypes.c_int32), ("collapse_mode", ctypes.c_int32),
-                ("flags", ctypes.c_int32)]
+                ("flags", ctypes.c_int32), ("dropout_keep", ctypes.c_int32), ("dropout_seed", ctypes.c_uint32)]
 
 
 _P = ctypes.c_void_p
@@ -117,7 +117,7 @@ class DpcLibrary(object):
         """True when the fused path keeps the xy-blurred grid (not G2) for backward at this shape
         (bit 3 of dpc_saved_layout): k_zfwd is then read-only, which bench.py's byte model needs to know."""
         shape = DpcShape(int(B), int(N), int(Dz or D), int(D), int(K), int(K), int(K))
-        params = DpcParams(2.0, 1.875, 1e-5, 10.0, 1, DPC_COLLAPSE_DRC, 0)
+        params = DpcParams(2.0, 1.875, 1e-5, 10.0, 1, DPC_COLLAPSE_DRC, 0, 0, 0)
         return bool(self.dpc_saved_layout(ctypes.byref(shape), ctypes.byref(params)) & 8)
 
     @staticmethod

@@ -368,16 +368,15 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   bool save_xy = false;
   if (plan.ok) {
     // 1+2 fused front end: transform + z-bucket (one WG per view) -> per-plane LDS splat + clip + x,y blur
-    int* order = (int*)point_index;                  // [B,N]   points sorted by depth cell
-    int* zstart = order + (size_t)S.B * S.N;         // [B,Dz+2] bucket starts
-    live = (unsigned*)(zstart + (size_t)S.B * (S.Dz + 2));   // [B,8] plane-occupancy bits
+    const PointIndex pi = point_index_views(S, point_index);
+    live = pi.live;
     // With the fused z pass as consumer, planes without mass are skipped end to end, and the xy-blurred
     // grid is what gets SAVED (in the grid_blur buffer): k_zfwd then only reads -- storing G2 was its
     // bottleneck -- and k_zbwd re-applies the z-FIR to the saved planes (DPC_SAVE_XY).
     save_xy = save_xy_mode(S, drc);
     float* xy_out = save_xy ? grid_blur : tmp;
-    rc = launch_splat_xy(st, S, P, plan, pc, pose, trans, focal, tr_pc, order, zstart, taps_x, taps_y, xy_out,
-                         clip_mask, live, drc && z_fixed(S.Kz));
+    rc = launch_splat_xy(st, S, P, plan, pc, pose, trans, focal, tr_pc, pi, taps_x, taps_y, xy_out, clip_mask,
+                         drc && z_fixed(S.Kz));
     if (rc) return rc;
     zin = xy_out;
     clip_in = 0;
@@ -467,14 +466,14 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   float* ds_acc = scale ? accum : nullptr;
   const int nzb = zbwd_blocks(S);
   // 1. collapse VJP (+ z-FIR adjoint) -> tA
-  const bool yx = use_cmask && plan.gSH > 0;   // consumer of tA is k_gather_yx (reads occupied planes only)
+  const bool yx = use_cmask;   // consumer of tA is k_gather_yx (reads occupied planes only)
+  PointIndex pi = {nullptr, nullptr, nullptr};
+  if (use_cmask) pi = point_index_views(S, point_index);
   if (zfused) {
-    const unsigned* live_all =
-        use_cmask ? (const unsigned*)(point_index + (size_t)S.B * S.N + (size_t)S.B * (S.Dz + 2)) : nullptr;
-    const unsigned* live = yx ? live_all : nullptr;
+    const unsigned* live = yx ? pi.live : nullptr;
     // fused forward (plan.ok): grid_blur holds the xy-blurred grid, see dpc_project_forward
     rc = launch_zbwd(st, S, P, grid_blur, taps_z, S.Kz, scale, ray_sums, dproj, dproj_depth, nullptr, tA,
-                     ds_acc, 1, live, scale ? dsparts : nullptr, accum, live_all, use_cmask && save_xy_mode(S, drc));
+                     ds_acc, 1, live, scale ? dsparts : nullptr, accum, pi.live, use_cmask && save_xy_mode(S, drc));
     if (rc) return rc;
   } else {
     float* first = (S.Kz > 0) ? tB : tA;
@@ -494,14 +493,12 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   }
   if (yx) {
     // 2+3 fused: per-plane LDS pass (y-blur + sparse x-blur + clip bits + trilinear gather),
-    // then the camera-transform VJP over the per-corner partials
-    const int* order = (const int*)point_index;
-    const int* zstart = order + (size_t)S.B * S.N;
-    rc = launch_gather_yx(st, S, plan, tA, tr_pc, order, zstart, clip_mask, taps_x, taps_y, parts);
+    // then the camera-transform VJP over the per-slot partials
+    rc = launch_gather_yx(st, S, plan, tA, pi, clip_mask, taps_x, taps_y, parts);
     if (rc) return rc;
-    return launch_points_bwd(st, S, P, pc, pose, trans, focal, tr_pc, nullptr, nullptr, nullptr, nullptr,
-                             dtr_pc_in, parts, false, dpc, dpose, dtrans, dfocal, scale ? dscale : nullptr,
-                             accum, false, (zfused && scale) ? dsparts : nullptr, nzb);
+    return launch_points_bwd_sorted(st, S, P, pc, pose, trans, focal, pi, dtr_pc_in, parts, dpc, dpose, dtrans,
+                                    dfocal, scale ? dscale : nullptr, accum, (zfused && scale) ? dsparts : nullptr,
+                                    nzb);
   }
   // 2. y-blur adjoint (dense) -> tB ; the x-blur is evaluated sparsely in step 3
   const float* dg = tA;
@@ -511,9 +508,9 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
     dg = tB;
   }
   // 3. sparse x-blur + clip mask + gather + transform VJP + reductions
-  return launch_points_bwd(st, S, P, pc, pose, trans, focal, tr_pc, dg, use_cmask ? nullptr : grid_raw,
-                           use_cmask ? clip_mask : nullptr, taps_x, dtr_pc_in, nullptr, true, dpc, dpose, dtrans,
-                           dfocal, scale ? dscale : nullptr, accum, false, (zfused && scale) ? dsparts : nullptr, nzb);
+  return launch_points_bwd(st, S, P, pc, pose, trans, focal, tr_pc, dg, grid_raw, nullptr, taps_x, dtr_pc_in, nullptr,
+                           true, dpc, dpose, dtrans, dfocal, scale ? dscale : nullptr, accum, false,
+                           (zfused && scale) ? dsparts : nullptr, nzb);
 }
 
 int dpc_silhouette_loss_fwd(dpc_stream_t stream, int B, int C, int D, int S, const float* proj, const float* gt,

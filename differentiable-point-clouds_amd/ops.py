@@ -14,7 +14,8 @@ from . import _capi
 from ._capi import DpcParams, DpcShape
 
 ProjMeta = collections.namedtuple(
-    "ProjMeta", "Dz D camera_distance focal_length eps max_depth pose_quaternion collapse_mode")
+    "ProjMeta", "Dz D camera_distance focal_length eps max_depth pose_quaternion collapse_mode dropout_keep dropout_seed",
+    defaults=(0, 0))
 
 
 # ---------------------------------------------------------------------------
@@ -62,7 +63,8 @@ def _shape(B, N, meta, K=(0, 0, 0)):
 
 def _params(meta):
     return DpcParams(float(meta.camera_distance), float(meta.focal_length), float(meta.eps),
-                     float(meta.max_depth), 1 if meta.pose_quaternion else 0, int(meta.collapse_mode), 0)
+                     float(meta.max_depth), 1 if meta.pose_quaternion else 0, int(meta.collapse_mode), 0,
+                     int(meta.dropout_keep), int(meta.dropout_seed) & 0xffffffff)
 
 
 def _check_points(pc, pose, trans, scale, focal, meta):

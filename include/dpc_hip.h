@@ -61,6 +61,12 @@ typedef struct DpcParams {
   int32_t pose_is_quaternion; /* 1: pose [B,4] (w,x,y,z); 0: [B,4,4] */
   int32_t collapse_mode;      /* DPC_COLLAPSE_*                    */
   int32_t flags;              /* reserved, 0                       */
+  /* fused point dropout (dpc/util/point_cloud.py:293-319): keep exactly `dropout_keep` of the N
+   * points of every instance, drawn without replacement, independently per instance, from the keyed
+   * permutation of (dropout_seed, instance); 0 or >= N = keep everything.  Only the fused path
+   * (dpc_saved_layout bit 1) honours it; dropped points get a zero gradient. */
+  int32_t dropout_keep;
+  uint32_t dropout_seed;
 } DpcParams;
 
 const char* dpc_version(void);
@@ -85,10 +91,12 @@ int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, 
  * [B,N,4] bytes, one bit per touched trilinear corner (fused path: points are
  * bucketed by depth cell and splatted into per-plane LDS tiles, the raw grid
  * never reaches HBM); bit 2 (value 4) = point_index, int32
- * [dpc_point_index_ints(shape)] = B*N + B*(Dz+2) + B*8: the points of each view
- * sorted by depth cell, the bucket starts, and 8 words of plane-occupancy bits
- * per view, which the backward re-uses (set together with bit 1).  Buffers
- * that are not used may be null.  <0 on error. */
+ * [dpc_point_index_ints(shape)] = 4*B*N + B*(Dz+2) + B*8 (16-byte aligned): the points of
+ * each view sorted by depth cell as 16-byte records (w, v, u, original index), the
+ * bucket starts, and 8 words of plane-occupancy bits per view, which the backward
+ * re-uses (set together with bit 1; clip_mask is indexed by the sorted slot);
+ * bit 3 (value 8, informational) = grid_blur holds the xy-blurred grid rather
+ * than G2.  Buffers that are not used may be null.  <0 on error. */
 int dpc_saved_layout(const DpcShape* shape, const DpcParams* params);
 /* Number of int32 elements of the point_index buffer (0 when the shape does not
  * use it). */

@@ -160,6 +160,29 @@ static inline float __shfl_xor(float v, int mask, int width = 64) {
   return r;
 }
 
+// DPP row shifts (v_mov_b32 dpp row_shl:n / row_shr:n, the controls the kernels use): rows of 16 lanes;
+// row_shr:n -- lane i reads lane i-n, row_shl:n -- lane i reads lane i+n; a lane without a source inside
+// its row gets 0 (bound_ctrl) or keeps `old`.  Lane mapping verified on MI355X (scripts/ubench/dpp_check.hip).
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  (void)row_mask; (void)bank_mask;
+  unsigned f = hipemu::t_ctx.flat;
+  memcpy(&hipemu::g_xchg[f], &src, 4);
+  hipemu::wave_sync();
+  const int lane = (int)(f & 63u), r = lane & 15;
+  int from = -1;
+  if (ctrl >= 0x101 && ctrl <= 0x10f) from = (r + (ctrl - 0x100) < 16) ? lane + (ctrl - 0x100) : -1;
+  else if (ctrl >= 0x111 && ctrl <= 0x11f) from = (r - (ctrl - 0x110) >= 0) ? lane - (ctrl - 0x110) : -1;
+  else abort();
+  unsigned nthreads = hipemu::t_ctx.bdim.x * hipemu::t_ctx.bdim.y * hipemu::t_ctx.bdim.z;
+  int res = bound_ctrl ? 0 : old;
+  if (from >= 0 && (f & ~63u) + (unsigned)from < nthreads) memcpy(&res, &hipemu::g_xchg[(f & ~63u) + (unsigned)from], 4);
+  hipemu::wave_sync();
+  return res;
+}
+static inline int __float_as_int(float v) { int r; memcpy(&r, &v, 4); return r; }
+static inline float __int_as_float(int v) { float r; memcpy(&r, &v, 4); return r; }
+static inline unsigned __float_as_uint(float v) { unsigned r; memcpy(&r, &v, 4); return r; }
+
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only used on wave-uniform values
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {

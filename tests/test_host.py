@@ -47,7 +47,7 @@ def test_c_abi_argument_validation_without_gpu():
     """Status codes are produced before any launch, so they can be checked here."""
     lib = _capi.DpcLibrary(_capi.LIB_PATH)
     S = _capi.DpcShape(2, 10, 8, 8, 4, 5, 5)           # even Kx
-    P = _capi.DpcParams(2.0, 1.875, 1e-5, 10.0, 1, 0, 0)
+    P = _capi.DpcParams(2.0, 1.875, 1e-5, 10.0, 1, 0, 0, 0, 0)
     assert lib.dpc_workspace_bytes(ctypes.byref(S), 0) == 0
     S = _capi.DpcShape(2, 10, 8, 8, 5, 5, 5)
     g = 2 * 8 * 8 * 8 * 4
@@ -55,7 +55,12 @@ def test_c_abi_argument_validation_without_gpu():
     assert lib.dpc_workspace_bytes(ctypes.byref(S), 0) % 256 == 0
     assert lib.dpc_saved_layout(ctypes.byref(S), ctypes.byref(P)) == 1      # D=8: generic path, dense grid_raw
     S64 = _capi.DpcShape(2, 10, 64, 64, 11, 11, 11)
-    assert lib.dpc_saved_layout(ctypes.byref(S64), ctypes.byref(P)) == 6    # fused path: clip_mask + point_index
+    assert lib.dpc_saved_layout(ctypes.byref(S64), ctypes.byref(P)) == 6 | 8   # fused path: clip_mask + point_index; xy grid saved
+    assert lib.dpc_point_index_ints(ctypes.byref(S64)) == 4 * 2 * 10 + 2 * 66 + 2 * 8
+    S21 = _capi.DpcShape(2, 10, 64, 64, 21, 21, 21)
+    assert lib.dpc_saved_layout(ctypes.byref(S21), ctypes.byref(P)) == 6       # 21 taps: G2 is what is saved
+    Sdeep = _capi.DpcShape(1, 10, 320, 32, 5, 5, 5)                            # Dz > 256: beyond the plane-occupancy words
+    assert lib.dpc_saved_layout(ctypes.byref(Sdeep), ctypes.byref(P)) == 1
     assert lib.dpc_workspace_bytes(ctypes.byref(S), 1) >= 2 * g
     null = None
     rc = lib.dpc_project_forward(null, ctypes.byref(S), ctypes.byref(P), *([null] * 16), null, 0)
