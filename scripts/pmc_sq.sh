@@ -14,7 +14,7 @@ for PASS in \
   "TCC_EA0_WRREQ_STALL_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" ; do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $PASS --kernel-trace -d "$OUT/pass$i" -o p --output-format csv -- \
-      python "$REPO/bench.py" --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline > "$OUT/pass$i.log" 2>&1
+      python "$REPO/bench.py" --gpus 1 --steps 4 --warmup 2 --repeats 0 --no-cpu-baseline $BENCH_ARGS > "$OUT/pass$i.log" 2>&1
   echo "pass $i exit $?"
 done
 cd "$REPO"
