@@ -54,6 +54,7 @@
 #include "hip_emu.h"  // tests/hipemu: a thread-per-lane model of the HIP API used below (CPU test tier only)
 #else
 #include <hip/hip_runtime.h>
+#include "k_asm_gfx950.inc"   // the few instructions hipcc will not pick on its own (tests/hipemu/hip_emu.h restates them)
 #endif
 
 // dynamic LDS of the kernel as a typed pointer (16-byte aligned base)
@@ -375,8 +376,9 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
     // bottleneck -- and k_zbwd re-applies the z-FIR to the saved planes (DPC_SAVE_XY).
     save_xy = save_xy_mode(S, drc);
     float* xy_out = save_xy ? grid_blur : tmp;
+    // (the depth sort's per-work-group histograms live at the head of the workspace until the splat runs)
     rc = launch_splat_xy(st, S, P, plan, pc, pose, trans, focal, tr_pc, pi, taps_x, taps_y, xy_out, clip_mask,
-                         drc && z_fixed(S.Kz));
+                         drc && z_fixed(S.Kz), workspace, workspace_bytes);
     if (rc) return rc;
     zin = xy_out;
     clip_in = 0;
@@ -467,7 +469,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   const int nzb = zbwd_blocks(S);
   // 1. collapse VJP (+ z-FIR adjoint) -> tA
   const bool yx = use_cmask;   // consumer of tA is k_gather_yx (reads occupied planes only)
-  PointIndex pi = {nullptr, nullptr, nullptr};
+  PointIndex pi = {nullptr, nullptr, nullptr, nullptr};
   if (use_cmask) pi = point_index_views(S, point_index);
   if (zfused) {
     const unsigned* live = yx ? pi.live : nullptr;
@@ -496,7 +498,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
     // then the camera-transform VJP over the per-slot partials
     rc = launch_gather_yx(st, S, plan, tA, pi, clip_mask, taps_x, taps_y, parts);
     if (rc) return rc;
-    return launch_points_bwd_sorted(st, S, P, pc, pose, trans, focal, pi, dtr_pc_in, parts, dpc, dpose, dtrans,
+    return launch_points_bwd_sorted(st, S, P, pc, pose, trans, focal, tr_pc, pi, dtr_pc_in, parts, dpc, dpose, dtrans,
                                     dfocal, scale ? dscale : nullptr, accum, (zfused && scale) ? dsparts : nullptr,
                                     nzb);
   }

@@ -91,9 +91,9 @@ int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, 
  * [B,N,4] bytes, one bit per touched trilinear corner (fused path: points are
  * bucketed by depth cell and splatted into per-plane LDS tiles, the raw grid
  * never reaches HBM); bit 2 (value 4) = point_index, int32
- * [dpc_point_index_ints(shape)] = 4*B*N + B*(Dz+2) + B*8 (16-byte aligned): the points of
- * each view sorted by depth cell as 16-byte records (w, v, u, original index), the
- * bucket starts, and 8 words of plane-occupancy bits per view, which the backward
+ * [dpc_point_index_ints(shape)] = 5*B*N + B*(Dz+2) + B*8 (16-byte aligned): the points of
+ * each view sorted by depth cell as 16-byte records (w, v, u, original index), the inverse
+ * map (slot of point n), the bucket starts, and 8 words of plane-occupancy bits per view, which the backward
  * re-uses (set together with bit 1; clip_mask is indexed by the sorted slot);
  * bit 3 (value 8, informational) = grid_blur holds the xy-blurred grid rather
  * than G2.  Buffers that are not used may be null.  <0 on error. */

@@ -6,7 +6,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -I../../in
 for n in 0 1 2 3 4; do
   /opt/rocm/bin/hipcc $FLAGS -DDPC_ABLATE_SPLAT=$n -o libdpc_abl_s$n.so dpc_kernels.hip &
 done
-for n in 0 1 2; do
+for n in 0 1 2 3; do
   /opt/rocm/bin/hipcc $FLAGS -DDPC_ABLATE_GATHER=$n -o libdpc_abl_g$n.so dpc_kernels.hip &
 done
 wait

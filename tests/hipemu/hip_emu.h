@@ -184,6 +184,14 @@ static inline int __float_as_int(float v) { int r; memcpy(&r, &v, 4); return r; 
 static inline float __int_as_float(int v) { float r; memcpy(&r, &v, 4); return r; }
 static inline unsigned __float_as_uint(float v) { unsigned r; memcpy(&r, &v, 4); return r; }
 
+// csrc/k_asm_gfx950.inc, restated
+typedef float dpc_v2f __attribute__((vector_size(8)));
+template <int SEL>
+static inline void dpc_pk_fma_tap(dpc_v2f& acc, dpc_v2f pair, dpc_v2f v) {
+  const dpc_v2f tt = dpc_v2f{pair[SEL], pair[SEL]};
+  acc += tt * v;
+}
+
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only used on wave-uniform values
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {

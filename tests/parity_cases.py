@@ -86,6 +86,7 @@ FUSED_CASES = [
     (2, 500, 64, 32, 11, 1.5, False, True),      # vox_size_z != vox_size: Kz = 5 (gauss_kernel.py:38-50)
     (2, 400, 64, 64, 21, 3.0, False, False),     # the shipped experiments' kernel size
     (2, 40, 64, 64, 5, 0.8, False, False),       # fewer points than one wave
+    (1, 8300, 32, 32, 5, 0.8, True, False),      # more than 8 x 1024 points: the two-kernel depth sort; > 512 points per plane
 ]
 
 
