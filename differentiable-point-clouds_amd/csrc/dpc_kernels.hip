@@ -285,18 +285,20 @@ int dpc_blur3d(dpc_stream_t stream, const DpcShape* shape, const float* in, floa
   if (!plane && !zed) return DPC_E_TAPS;
   if (plane && zed && !tmp) return DPC_E_NULL;
   hipStream_t st = (hipStream_t)stream;
+  // order 1 = the adjoint of order 0: passes in reverse order, every tap vector reversed
+  const int rev = order != 0;
   if (plane && zed) {
     if (order == 0) {
       rc = launch_blur_plane(st, S, in, tmp, taps_x, taps_y, S.Kx, S.Ky, 0);
       if (rc) return rc;
       return launch_blur_z(st, S, tmp, out, taps_z, S.Kz);
     }
-    rc = launch_blur_z(st, S, in, tmp, taps_z, S.Kz);
+    rc = launch_blur_z(st, S, in, tmp, taps_z, S.Kz, 1);
     if (rc) return rc;
-    return launch_blur_plane(st, S, tmp, out, taps_x, taps_y, S.Kx, S.Ky, 0);
+    return launch_blur_plane(st, S, tmp, out, taps_x, taps_y, S.Kx, S.Ky, 0, 1);
   }
-  if (plane) return launch_blur_plane(st, S, in, out, taps_x, taps_y, S.Kx, S.Ky, 0);
-  return launch_blur_z(st, S, in, out, taps_z, S.Kz);
+  if (plane) return launch_blur_plane(st, S, in, out, taps_x, taps_y, S.Kx, S.Ky, 0, rev);
+  return launch_blur_z(st, S, in, out, taps_z, S.Kz, rev);
 }
 
 int dpc_drc_fwd(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* voxels,
@@ -489,7 +491,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
     }
     if (rc) return rc;
     if (S.Kz > 0) {
-      rc = launch_blur_z(st, S, tB, tA, taps_z, S.Kz);
+      rc = launch_blur_z(st, S, tB, tA, taps_z, S.Kz, 1);
       if (rc) return rc;
     }
   }
@@ -505,7 +507,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   // 2. y-blur adjoint (dense) -> tB ; the x-blur is evaluated sparsely in step 3
   const float* dg = tA;
   if (S.Ky > 0) {
-    rc = launch_blur_plane(st, S, tA, tB, nullptr, taps_y, 0, S.Ky, 0);
+    rc = launch_blur_plane(st, S, tA, tB, nullptr, taps_y, 0, S.Ky, 0, 1);
     if (rc) return rc;
     dg = tB;
   }

@@ -91,6 +91,28 @@ class ModelPointCloud(object):
     def get_dropout_keep_prob(self):
         return get_dropout_prob(self.cfg(), self._global_step)
 
+    def _fused_dropout_ok(self, all_points, all_rgb):
+        """The fused draw needs the fast projector's fused path, no colour channels and a losses set that
+        does not fetch the dense grids (cfg.pc_fused_dropout=False forces the explicit gather)."""
+        cfg = self.cfg()
+        if not cfg.pc_fast or all_rgb is not None or not getattr(cfg, "pc_fused_dropout", True):
+            return False
+        if getattr(cfg, "drc_weight", 0.0):     # add_drc_loss fetches drc_probs (stage-level kernels, all N points)
+            return False
+        from .util.point_cloud import _flat_taps, _meta
+        taps = _flat_taps(cfg, self.gauss_kernel(), all_points.device)
+        K = tuple(0 if t is None else int(t.numel()) for t in taps)
+        return ops.uses_fused_path(ops._capi.get_library(), all_points.shape[0], all_points.shape[1], _meta(cfg), K)
+
+    def _next_dropout_seed(self):
+        """One 32-bit seed per step from a host-side LCG started at torch's seed: no device work, no sync."""
+        s = getattr(self, "_dropout_seed", None)
+        if s is None:
+            s = torch.initial_seed() & 0xffffffff
+        s = (s * 1664525 + 1013904223) & 0xffffffff
+        self._dropout_seed = s
+        return s
+
     def replicate_for_multiview(self, tensor):                # model_pc.py:261-264
         return tf_repeat_0(tensor, self.cfg().step_size)
 
@@ -132,13 +154,19 @@ class ModelPointCloud(object):
             camera_pose = inputs["camera_quaternion"]
         else:
             camera_pose = inputs["matrices"]
+        point_dropout = None
         if is_training and cfg.pc_point_dropout != 1:                      # model_pc.py:233-237
-            all_points, all_rgb = pc_point_dropout(all_points, all_rgb, self.get_dropout_keep_prob())
+            keep_prob = self.get_dropout_keep_prob()
+            if self._fused_dropout_ok(all_points, all_rgb):
+                # the draw happens inside the projector's depth sort (no [B,N',3] copy, no argsort)
+                point_dropout = (int(all_points.shape[1] * float(keep_prob)), self._next_dropout_seed())
+            else:
+                all_points, all_rgb = pc_point_dropout(all_points, all_rgb, keep_prob)
         if cfg.pc_fast:
             predicted_translation = outputs["predicted_translation"] if cfg.predict_translation else None
             proj_out = pointcloud_project_fast(cfg, all_points, camera_pose, predicted_translation, all_rgb,
                                                self.gauss_kernel(), scaling_factor=outputs["all_scaling_factors"],
-                                               focal_length=outputs["all_focal_length"])
+                                               focal_length=outputs["all_focal_length"], point_dropout=point_dropout)
             proj = proj_out["proj"]
             outputs["projs_rgb"] = proj_out["proj_rgb"]
             # TF1 only computes drc_probs ([Dz+1,B,D,D,1]) if a loss fetches it; here it is

@@ -109,6 +109,13 @@ def _taps_of(taps):
     return tuple(ts), tuple(ks)
 
 
+def uses_fused_path(lib, B, N, meta, K):
+    """True when this shape takes the fused front/back end (depth-sorted points, per-plane LDS tiles): the
+    only path that honours the fused point dropout."""
+    shape, params = _shape(B, N, meta, K), _params(meta)
+    return bool(lib.dpc_saved_layout(ctypes.byref(shape), ctypes.byref(params)) & 2)
+
+
 _POISON = bool(os.environ.get("DPC_POISON_BUFFERS"))        # read once: this sits on the per-step host path
 
 
@@ -151,6 +158,9 @@ class ProjectFused(torch.autograd.Function):
         tr_pc = new(B, N, 3)
         layout = lib.dpc_saved_layout(ctypes.byref(shape), ctypes.byref(params))
         lib.check(min(layout, 0), "dpc_saved_layout")
+        if 0 < meta.dropout_keep < N and not layout & 2:
+            raise ValueError("fused point dropout needs the fused path (power-of-two vox_size in [32,256], kernel size "
+                             "5/11/21, vox_size_z <= 256); use pc_point_dropout for this shape")
         grid_raw = new(B, Dz, D, D) if layout & 1 else None
         clip_mask = new(B, N, 4, dtype=torch.uint8) if layout & 2 else None
         point_index = new(lib.dpc_point_index_ints(ctypes.byref(shape)), dtype=torch.int32) if layout & 4 else None
@@ -194,7 +204,8 @@ class ProjectFused(torch.autograd.Function):
         dpose = torch.empty_like(pose)
         dtrans = new(B, 3) if trans is not None else None
         dscale = new(B) if scale is not None else None
-        dfocal = new(B) if focal is not None else None
+        # the matrix branch never reads the per-instance focal length (point_cloud.py:191-205): no gradient
+        dfocal = new(B) if (focal is not None and meta.pose_quaternion) else None
         ws = _Workspace(lib, shape, 1, pc)
         rc = lib.dpc_project_backward(_stream(lib, pc), ctypes.byref(shape), ctypes.byref(params),
                                       _p(pc), _p(pose), _p(trans), _p(scale), _p(focal),
@@ -242,7 +253,8 @@ class Transform(torch.autograd.Function):
         dpc = torch.empty_like(pc)
         dpose = torch.empty_like(pose)
         dtrans = torch.empty_like(trans) if trans is not None else None
-        dfocal = torch.empty(B, dtype=torch.float32, device=pc.device) if focal is not None else None
+        dfocal = (torch.empty(B, dtype=torch.float32, device=pc.device)
+                  if (focal is not None and ctx.meta.pose_quaternion) else None)
         scratch = torch.empty(B * 16, dtype=torch.float32, device=pc.device)
         rc = lib.dpc_transform_bwd(_stream(lib, pc), ctypes.byref(shape), ctypes.byref(params),
                                    _p(pc), _p(pose), _p(trans), _p(focal), _p(dtr),
@@ -351,6 +363,7 @@ class Blur3d(torch.autograd.Function):
         taps = [saved.pop(0) if p else None for p in ctx.present]
         dout = _c(dout)
         lib = _lib_for(dout)
+        # order 1 = the adjoint: z first, every tap vector reversed inside the kernels (asymmetric filters too)
         return _blur(lib, dout, taps, ctx.K, 1), None, None, None
 
 
@@ -425,8 +438,24 @@ class SilhouetteLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, proj, gt, valid, num_candidates):
         lib = _lib_for(proj)
+        C = int(num_candidates)
+        if proj.dim() != 4 or proj.shape[1] != proj.shape[2] or proj.shape[3] != 1:
+            raise ValueError("proj must be [B,D,D,1], got %s" % (tuple(proj.shape),))
+        B, D = proj.shape[0], proj.shape[1]
+        if C <= 0 or B % C != 0:
+            raise ValueError("B=%d instances do not split into groups of %d pose candidates" % (B, C))
+        if gt.dim() != 4 or gt.shape[0] != B // C or gt.shape[1] != gt.shape[2] or gt.shape[3] != 1:
+            raise ValueError("gt must be [%d,S,S,1] (one mask per (model, view)), got %s" % (B // C, tuple(gt.shape)))
+        if gt.shape[1] < D:
+            raise ValueError("GT size should not be lower than the prediction size")
+        # masks arrive as uint8 / bool / float64 from data pipelines: the kernels read float32 on proj's device
+        gt = gt.to(device=proj.device, dtype=torch.float32)
+        if valid is not None:
+            if valid.numel() != B // C:
+                raise ValueError("valid_samples must have %d elements, got %d" % (B // C, valid.numel()))
+            valid = valid.to(device=proj.device, dtype=torch.float32)
+        lib = _lib_for(proj, gt, valid)
         proj, gt = _c(proj), _c(gt)
-        B, D, C = proj.shape[0], proj.shape[1], int(num_candidates)
         S = gt.shape[1]
         dev = proj.device
         if valid is not None:

@@ -191,16 +191,29 @@ class ProjectionOutputs(dict):
 
 
 def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
-                            all_rgb, kernel=None, scaling_factor=None, focal_length=None):
-    """dpc/util/point_cloud.py:229-290."""
+                            all_rgb, kernel=None, scaling_factor=None, focal_length=None, *, point_dropout=None):
+    """dpc/util/point_cloud.py:229-290.
+
+    ``point_dropout=(num_keep, seed)`` (keyword-only, not in the reference signature) fuses
+    pc_point_dropout (point_cloud.py:293-319) into the projector: every instance keeps exactly
+    ``num_keep`` of its N points, drawn without replacement from a permutation keyed by (seed,
+    instance), inside the depth sort -- no [B,N',3] copy of the cloud, dropped points get a zero
+    gradient.  ``tr_pc`` then still holds all N transformed points."""
     _drc._check_cfg(cfg)
     meta = _meta(cfg)
+    if point_dropout is not None:
+        if all_rgb is not None:
+            raise NotImplementedError("fused point dropout with colour channels: use pc_point_dropout")
+        meta = meta._replace(dropout_keep=int(point_dropout[0]), dropout_seed=int(point_dropout[1]) & 0xffffffff)
     tx, ty, tz = _flat_taps(cfg, kernel, point_cloud.device)
     proj, proj_depth, tr_pc = ops.ProjectFused.apply(point_cloud, transform, predicted_translation,
                                                      scaling_factor, focal_length, tx, ty, tz, meta)
     state = {}
 
     def make_voxels():
+        if point_dropout is not None and 0 < meta.dropout_keep < point_cloud.shape[1]:
+            raise NotImplementedError("'voxels' / 'drc_probs' of a projection with fused point dropout "
+                                      "(the stage-level kernels see all N points): use pc_point_dropout")
         if "voxels" not in state:
             v, _ = pointcloud2voxels3d_fast(cfg, tr_pc, None)
             v = torch.clamp(v, 0.0, 1.0)

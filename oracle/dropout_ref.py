@@ -1,0 +1,52 @@
+"""TEST INFRASTRUCTURE -- NumPy restatement of the fused point dropout's keyed permutation
+(differentiable-point-clouds_amd/csrc/k_fused.inc: dpc_mix32, dropout_rank), so that tests can predict which
+points an instance keeps and compare the fused path with the projector run on that explicit subset.
+
+Reference semantics being reproduced (dpc/util/point_cloud.py:293-319): every instance keeps
+int(N * keep_prob) of its N points, drawn without replacement, independently of the other instances.
+The reference draws with np.random.choice inside a tf.py_func; here the draw is a 4-round Feistel permutation
+of [0, N) keyed by (seed, instance) and point n survives iff its image is < keep.
+
+Only tests/ import this module.
+"""
+import numpy as np
+
+_M = np.uint64(0xFFFFFFFF)
+
+
+def _mix32(x):
+    x = x.astype(np.uint64) & _M
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x85EBCA6B)) & _M
+    x ^= x >> np.uint64(13)
+    x = (x * np.uint64(0xC2B2AE35)) & _M
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def dropout_rank(N, seed, b):
+    """pi_b(n) for n = 0..N-1 (uint64 array): a permutation of [0, N)."""
+    half = 1
+    while (1 << (2 * half)) < N:
+        half += 1
+    mask = np.uint64((1 << half) - 1)
+    key = _mix32(np.array([(int(seed) ^ ((b * 0x9E3779B9 + 0x7F4A7C15) & 0xFFFFFFFF)) & 0xFFFFFFFF], np.uint64))[0]
+    x = np.arange(N, dtype=np.uint64)
+    todo = np.ones(N, dtype=bool)
+    while todo.any():
+        xs = x[todo]
+        L, R = xs >> np.uint64(half), xs & mask
+        for r in range(4):
+            F = _mix32((R + key + np.uint64((r * 0x632BE5AB) & 0xFFFFFFFF)) & _M) & mask
+            L, R = R, L ^ F
+        xs = (L << np.uint64(half)) | R
+        x[todo] = xs
+        todo[todo] = xs >= np.uint64(N)
+    return x
+
+
+def kept_mask(B, N, keep, seed):
+    """[B, N] bool: which points survive the fused dropout with this (keep, seed)."""
+    if keep <= 0 or keep >= N:
+        return np.ones((B, N), dtype=bool)
+    return np.stack([dropout_rank(N, seed, b) < np.uint64(keep) for b in range(B)])

@@ -103,3 +103,18 @@ def relerr(a, b):
     """max-abs error relative to the largest reference magnitude."""
     b = np.asarray(b, np.float64)
     return maxabs(a, b) / max(float(np.max(np.abs(b))), 1e-30)
+
+
+def close_elementwise(a, b, rtol=1e-3, atol_frac=2e-5):
+    """ELEMENTWISE gradient check: |a - b| <= atol + rtol |b| at every entry, with the absolute floor tied to the
+    tensor's scale (atol = atol_frac * max|b|: an fp32 gradient entry is a sum of cancelling terms of that size,
+    so its absolute rounding error is of the order of 1e-7 max|b| per term regardless of how small the entry is).
+    A small entry that is 100 % wrong fails, unlike with a max-abs/max-magnitude ratio.
+    Returns (ok, worst excess ratio)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64).reshape(a.shape)
+    scale = max(float(np.max(np.abs(b))), 1e-30) if b.size else 1.0
+    bound = atol_frac * scale + rtol * np.abs(b)
+    ratio = np.abs(a - b) / bound
+    worst = float(ratio.max()) if ratio.size else 0.0
+    return worst <= 1.0, worst

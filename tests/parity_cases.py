@@ -336,3 +336,146 @@ def fused_edge_planes_against_numpy_oracle(dev):
     for name, g in zip(("dpc", "dpose", "dscale"), grads):
         assert relerr(g.cpu().numpy().reshape(bw[name].shape), bw[name]) < TOL_GRAD, name
     assert float(grads[0][0].abs().max()) == 0.0                              # outliers get no gradient
+
+
+# ---------------------------------------------------------------------------
+# round-2 cases
+# ---------------------------------------------------------------------------
+def _asym_kernel(K, seed, dtype, dev="cpu"):
+    """Three DIFFERENT, ASYMMETRIC, normalised separable filters in the reference's conv3d filter layout."""
+    rng = np.random.default_rng(seed)
+    ks = []
+    for shape in ((1, 1, K, 1, 1), (1, K, 1, 1, 1), (K, 1, 1, 1, 1)):
+        t = rng.uniform(0.05, 1.0, K) * np.linspace(0.3, 1.7, K)      # skewed to one side
+        t = (t / t.sum()).astype(np.float32)
+        ks.append(torch.tensor(t.reshape(shape), dtype=dtype, device=dev))
+    return ks
+
+
+ASYM_CASES = [(32, 5), (24, 5), (24, 7)]       # fused path; generic plane path with fixed z taps; run-time taps
+
+
+def asymmetric_filters_against_cpu_oracle(dev, D, K):
+    """smoothen_voxels3d / pointcloud_project_fast accept ARBITRARY separable filters (conv3d is a
+    cross-correlation): forward and every gradient with three different skewed filters against the
+    torch-CPU restatement of the reference graph.  A backward pass that re-applied the forward taps
+    unreversed (correct only for symmetric Gaussians) fails this by ~100 %."""
+    from helpers import close_elementwise
+    B, N = 2, 300
+    inp = synth.make_inputs(B, N, 4100 + D + K)
+    inp = _nudge_off_cell_faces(inp, None, None, D, D)
+    cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K)
+    rc = rcpu.Cfg(vox_size=D, pc_gauss_kernel_size=K)
+    kern = _asym_kernel(K, 7 + D, torch.float32, dev)
+    ckern = _asym_kernel(K, 7 + D, torch.float64)
+    t = lambda a: torch.tensor(a, device=dev, requires_grad=True)
+    pc, pose, scale = t(inp["pc"]), t(inp["pose"]), t(inp["scale"])
+    c = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    cpc, cpose, cscale = c(inp["pc"]), c(inp["pose"]), c(inp["scale"])
+    out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale)
+    ref = rcpu.pointcloud_project_fast(rc, cpc, cpose, None, None, ckern, scaling_factor=cscale)
+    assert maxabs(out["proj"].detach().cpu().numpy(), ref["proj"].detach().numpy()) < TOL_PROJ
+    w = np.random.default_rng(D).standard_normal(tuple(out["proj"].shape))
+    g = torch.autograd.grad(out["proj"], [pc, pose, scale], torch.tensor(w, dtype=torch.float32, device=dev))
+    rg = torch.autograd.grad(ref["proj"], [cpc, cpose, cscale], torch.tensor(w))
+    for name, a, b in zip(("dpc", "dpose", "dscale"), g, rg):
+        ok, worst = close_elementwise(a.cpu().numpy(), b.numpy(), rtol=2e-3, atol_frac=5e-5)
+        assert ok, (name, worst)
+    # stage-level blur and its adjoint with the same filters
+    vox = torch.tensor(np.random.default_rng(1).uniform(0, 1, (B, D, D, D, 1)).astype(np.float32), device=dev,
+                       requires_grad=True)
+    cvox = vox.detach().cpu().double().requires_grad_(True)
+    sm = dpc_amd.smoothen_voxels3d(cfg, vox, kern)
+    csm = rcpu.smoothen_voxels3d(rc, cvox, ckern)
+    assert maxabs(sm.detach().cpu().numpy(), csm.detach().numpy()) < 1e-5
+    wv = np.random.default_rng(2).standard_normal(tuple(sm.shape))
+    gv, = torch.autograd.grad(sm, [vox], torch.tensor(wv, dtype=torch.float32, device=dev))
+    cgv, = torch.autograd.grad(csm, [cvox], torch.tensor(wv))
+    assert maxabs(gv.cpu().numpy(), cgv.numpy()) < 2e-5 * float(np.abs(cgv.numpy()).max())
+
+
+def fused_dropout_equals_explicit_subset(dev, B=3, N=420, D=32, K=5, keep=137, seed=20260927):
+    """pointcloud_project_fast(point_dropout=(keep, seed)) == the projector run on the explicitly gathered
+    subset that oracle/dropout_ref.py predicts (per-instance, exactly `keep` points, without replacement):
+    forward image, gradients of the kept points, exact zeros for the dropped ones."""
+    from oracle import dropout_ref
+    inp = synth.make_inputs(B, N, 5150)
+    cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K)
+    kern = dpc_amd.smoothing_kernel(cfg, 0.9, device=dev)
+    t = lambda a: torch.tensor(a, device=dev, requires_grad=True)
+    pc, pose, scale = t(inp["pc"]), t(inp["pose"]), t(inp["scale"])
+    out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale,
+                                          point_dropout=(keep, seed))
+    w = torch.tensor(np.random.default_rng(9).standard_normal(tuple(out["proj"].shape)).astype(np.float32), device=dev)
+    g = torch.autograd.grad(out["proj"], [pc, pose, scale], w)
+
+    mask = dropout_ref.kept_mask(B, N, keep, seed)
+    assert (mask.sum(1) == keep).all() and not (mask[0] == mask[1]).all()      # exact count, per-instance draws
+    idx = np.stack([np.nonzero(m)[0] for m in mask])                            # [B, keep]
+    sub = torch.tensor(np.take_along_axis(inp["pc"], idx[:, :, None], axis=1), device=dev, requires_grad=True)
+    pose2, scale2 = t(inp["pose"]), t(inp["scale"])
+    ref = dpc_amd.pointcloud_project_fast(cfg, sub, pose2, None, None, kern, scaling_factor=scale2)
+    rg = torch.autograd.grad(ref["proj"], [sub, pose2, scale2], w)
+    # integer (order-independent) splat + identical blur / collapse kernels: the images agree to rounding of
+    # nothing at all; allow one ulp-level slack for the block-reduction order of the pose sums only
+    assert float((out["proj"] - ref["proj"]).abs().max()) <= 1e-7
+    gpc = g[0].cpu().numpy()
+    assert np.all(gpc[~mask] == 0.0)                                            # dropped points: exactly zero
+    assert maxabs(np.take_along_axis(gpc, idx[:, :, None], axis=1), rg[0].cpu().numpy()) <= 1e-7 * max(1.0, float(np.abs(gpc).max()))
+    assert relerr(g[1].cpu().numpy(), rg[1].cpu().numpy()) < 1e-5
+    assert relerr(g[2].cpu().numpy(), rg[2].cpu().numpy()) < 1e-5
+    assert out["tr_pc"].shape == (B, N, 3)
+    # keep >= N and keep == 0 mean "no dropout"
+    full = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale, point_dropout=(N, 1))
+    plain = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale)
+    assert float((full["proj"] - plain["proj"]).abs().max()) == 0.0
+
+
+def knife_edge_inputs_match_reference_conventions(dev, D, Dz):
+    """NO nudging: points that sit EXACTLY on lattice nodes / cell faces / the faces of the unit cube, a node
+    that receives exactly 1.0 (clip_by_value(G0,0,1) must still pass its gradient: closed interval), a node
+    that receives 2.0 (gradient blocked), coincident points.  Identity pose and depth -0.125 make the
+    perspective divide exact in fp32 (Z = 1.875 = focal length), so the fp32 lattice coordinates are the
+    same bits in the product and in the fp32 CPU restatement of the reference graph, and the piecewise
+    choices (floor, the closed validity test -0.5 <= p <= 0.5, the closed clip interval) are compared one to one."""
+    f = 1.0 / (D - 1)
+    fz = 1.0 / (Dz - 1)
+    nodes_xy = [-0.5, 0.5] + ([-0.5 + 8 * f, -0.5 + 9 * f] if (D - 1) & (D - 2) == 0 else [])   # exact iff D-1 = 2^k
+    zs = [-0.125, -0.5, 0.5] + ([-0.5 + 5 * fz] if (Dz - 1) & (Dz - 2) == 0 else [])
+    pts = []
+    for y in nodes_xy + [0.1]:
+        for x in nodes_xy + [-0.2]:
+            pts.append((-0.125, y, x))
+    for z in zs:
+        pts.append((z, 0.25, -0.25))
+    pts += [(-0.125, -0.5, -0.5)] * 1                # second point on the corner node: G0 = 2 there
+    pts += [(-0.125, 0.5, -0.5), (-0.125, 0.5000001, 0.0), (0.50000006, 0.0, 0.0)]   # just outside: dropped
+    pts += [(-0.125, 0.3, 0.3), (-0.125, 0.3, 0.3)]  # coincident interior points
+    pc_np = np.array(pts, dtype=np.float32)[None]
+    B, N = 1, pc_np.shape[1]
+    pose_np = np.array([[1.0, 0.0, 0.0, 0.0]], dtype=np.float32)
+    K = 5
+    cfg = dpc_amd.default_config(vox_size=D, vox_size_z=(Dz if Dz != D else -1), pc_gauss_kernel_size=K)
+    rc = rcpu.Cfg(vox_size=D, vox_size_z=(Dz if Dz != D else -1), pc_gauss_kernel_size=K)
+    pc = torch.tensor(pc_np, device=dev, requires_grad=True)
+    pose = torch.tensor(pose_np, device=dev, requires_grad=True)
+    cpc = torch.tensor(pc_np, requires_grad=True)                      # fp32 on purpose: same knife-edge decisions
+    cpose = torch.tensor(pose_np, requires_grad=True)
+    out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, dpc_amd.smoothing_kernel(cfg, 0.7, device=dev))
+    ref = rcpu.pointcloud_project_fast(rc, cpc, cpose, None, None, rcpu.smoothing_kernel(rc, 0.7, torch.float32))
+    assert maxabs(out["tr_pc"].detach().cpu().numpy(), ref["tr_pc"].detach().numpy()) == 0.0   # bit-identical coordinates
+    assert maxabs(out["proj"].detach().cpu().numpy(), ref["proj"].detach().numpy()) < TOL_PROJ
+    w = np.random.default_rng(D + Dz).standard_normal(tuple(out["proj"].shape)).astype(np.float32)
+    g = torch.autograd.grad(out["proj"], [pc, pose], torch.tensor(w, device=dev))
+    rg = torch.autograd.grad(ref["proj"], [cpc, cpose], torch.tensor(w))
+    gpc, rgpc = g[0].cpu().numpy()[0], rg[0].numpy()[0]
+    scale_ = float(np.abs(rgpc).max())
+    assert np.abs(gpc - rgpc).max() < 2e-4 * scale_, np.abs(gpc - rgpc).max() / scale_
+    # the point just outside the closed cube (v = 0.50000012) is dropped: exactly zero gradient in both; its
+    # neighbour ON the face (v = +0.5 exactly) is not
+    assert pts[-4] == (-0.125, 0.5000001, 0.0) and np.all(rgpc[-4] == 0.0) and np.all(gpc[-4] == 0.0)
+    assert np.abs(rgpc[-5]).max() > 0 and np.abs(gpc[-5]).max() > 0
+    # the single point on the far corner node (+0.5, +0.5) is INSIDE (closed test) and its node holds exactly 1.0:
+    # its gradient is not blocked by the clip
+    k = len(nodes_xy + [0.1]) * 1 + 1                                   # (y = +0.5, x = +0.5)
+    assert pts[k] == (-0.125, 0.5, 0.5) and np.abs(rgpc[k]).max() > 0 and np.abs(gpc[k]).max() > 0

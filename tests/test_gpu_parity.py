@@ -270,3 +270,139 @@ def test_cfg5_stress_shape_runs():
     assert abs(float(proj.min()) - 2.557e-3) < 6e-6
     g = torch.autograd.grad(proj, [pc, pose, scale], torch.ones_like(proj) / proj.numel())
     assert all(torch.isfinite(x).all() for x in g)
+
+
+# ---------------------------------------------------------------------------
+# round 2
+# ---------------------------------------------------------------------------
+from helpers import close_elementwise  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_focal", "tiny_matrix", "k21", "cfg1", "mid"])
+def test_point_gradients_elementwise(name):
+    """dpc entry by entry against the fp64 goldens: |err| <= 2e-5 max|ref| + 1e-3 |ref| (a small entry that is
+    100 % wrong fails; the max-abs / max-magnitude ratio of test_goldens would let it through)."""
+    g = load(name)
+    _, gr = run_product(name, g, "cuda", grads=True)
+    ok, worst = close_elementwise(gr["dpc"], g["dpc_f64"])
+    assert ok, worst
+
+
+@pytest.mark.parametrize("D,K", parity_cases.ASYM_CASES + [(64, 21), (128, 11)])
+def test_asymmetric_filters(D, K):
+    parity_cases.asymmetric_filters_against_cpu_oracle("cuda", D, K)
+
+
+def test_fused_dropout():
+    parity_cases.fused_dropout_equals_explicit_subset("cuda")
+    parity_cases.fused_dropout_equals_explicit_subset("cuda", B=5, N=8000, D=64, K=21, keep=560, seed=77)
+    parity_cases.fused_dropout_equals_explicit_subset("cuda", B=2, N=9000, D=64, K=11, keep=4500, seed=3)   # two-kernel sort
+
+
+@pytest.mark.parametrize("D,Dz", [(32, 33), (64, 65), (33, 33)])
+def test_knife_edges_without_nudging(D, Dz):
+    parity_cases.knife_edge_inputs_match_reference_conventions("cuda", D, Dz)
+
+
+def _against_reference_cpu(c, B, dev="cuda", chunk=None):
+    """HIP fwd+bwd on B views of a synthetic config against oracle/reference_cpu.py (fp64) on the SAME views.
+    The function is only piecewise smooth (cell faces, the clip at G0 = 1): with ~10^5 points a handful sit
+    within fp32 rounding of such an edge and the fp32 path may legitimately take the other piece than fp64, so
+    those points are moved off the edges first (the conventions AT the edges are pinned, un-nudged, by
+    test_knife_edges_without_nudging)."""
+    c = dict(c)
+    c["pc"] = parity_cases._nudge_off_cell_faces({"pc": c["pc"], "pose": c["pose"]}, None, None, c["D"], c["D"])["pc"]
+    cfg = dpc_amd.default_config(vox_size=c["D"], pc_gauss_kernel_size=c["K"])
+    t = lambda a: torch.tensor(a, device=dev, requires_grad=True)
+    pc, pose, scale = t(c["pc"]), t(c["pose"]), t(c["scale"])
+    kern = dpc_amd.smoothing_kernel(cfg, c["sigma"], device=dev)
+    out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale)
+    gt = torch.tensor(synth.disk_gt(B, c["D"]), device=dev)
+    dproj = ((out["proj"] - gt) / B).detach()
+    g = torch.autograd.grad(out["proj"], [pc, pose, scale], dproj)
+    rc = rcpu.Cfg(vox_size=c["D"], pc_gauss_kernel_size=c["K"])
+    ckern = rcpu.smoothing_kernel(rc, c["sigma"], torch.float64)
+    chunk = chunk or B
+    worst = {}
+    for lo in range(0, B, chunk):
+        hi = min(B, lo + chunk)
+        d = lambda a: torch.tensor(a[lo:hi], dtype=torch.float64, requires_grad=True)
+        cpc, cpose, cscale = d(c["pc"]), d(c["pose"]), d(c["scale"])
+        ref = rcpu.pointcloud_project_fast(rc, cpc, cpose, None, None, ckern, scaling_factor=cscale)
+        rg = torch.autograd.grad(ref["proj"], [cpc, cpose, cscale], dproj[lo:hi].cpu().double())
+        e = {"proj": maxabs(out["proj"][lo:hi].detach().cpu().numpy(), ref["proj"].detach().numpy()),
+             "depth": maxabs(out["proj_depth"][lo:hi].detach().cpu().numpy(), ref["proj_depth"].detach().numpy()),
+             "dpc": relerr(g[0][lo:hi].cpu().numpy(), rg[0].numpy()),
+             "dpose": relerr(g[1][lo:hi].cpu().numpy(), rg[1].numpy()),
+             "dscale": relerr(g[2][lo:hi].cpu().numpy(), rg[2].numpy())}
+        for k, v in e.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+    assert worst["proj"] < TOL_PROJ and worst["depth"] < TOL_DEPTH, worst
+    assert worst["dpc"] < TOL_GRAD and worst["dpose"] < TOL_GRAD and worst["dscale"] < TOL_GRAD, worst
+    return worst
+
+
+def test_cfg2_full_batch_against_cpu_oracle():
+    """BASELINE configs[1] at its FULL batch (32 views x 8000 pts, 128^3, K=11): every view against the
+    torch-CPU restatement of the reference graph (fp64), forward and all gradients."""
+    _against_reference_cpu(synth.config_inputs(2), 32, chunk=8)
+
+
+def test_cfg5_full_batch_against_cpu_oracle():
+    """BASELINE configs[4] at its FULL size (8 views x 16000 pts, 256^3, K=11, sigma 2.0)."""
+    _against_reference_cpu(synth.config_inputs(5), 8, chunk=1)
+
+
+TRAIN_SHAPE = dict(B=320, D=64, K=21, sigma=3.0)    # configs[2]: 16 models x 5 views x 4 pose candidates
+
+
+@pytest.mark.parametrize("N", [560, 4000, 8000])      # the dropout schedule's point counts (keep 0.07 -> 1.0)
+def test_training_shape_projector(N):
+    """The projector at the shape the reference trains with (B=320, 64^3, K=21): properties at the full batch,
+    the CPU oracle on a slice of 8 views."""
+    synth.CONFIGS[3] = dict(TRAIN_SHAPE, N=N)
+    c = synth.config_inputs(3)
+    cfg = dpc_amd.default_config(vox_size=64, pc_gauss_kernel_size=21)
+    t = lambda a: torch.tensor(a, device="cuda", requires_grad=True)
+    pc, pose, scale = t(c["pc"]), t(c["pose"]), t(c["scale"])
+    kern = dpc_amd.smoothing_kernel(cfg, c["sigma"], device="cuda")
+    out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale)
+    proj = out["proj"]
+    assert proj.shape == (320, 64, 64, 1) and torch.isfinite(proj).all()
+    assert float(proj.min()) >= 6.39e-4 - 3e-6 and float(proj.max()) <= 1.0 + 1e-5      # 1-(1-eps)^64 = 6.40e-4
+    gt = torch.tensor(synth.disk_gt(320, 64), device="cuda")
+    g = torch.autograd.grad(proj, [pc, pose, scale], ((proj - gt) / 320).detach())
+    assert all(torch.isfinite(x).all() for x in g)
+    tr = out["tr_pc"].detach()
+    invalid = ~((tr >= -0.5) & (tr <= 0.5)).all(-1)
+    assert float(g[0][invalid].abs().max()) == 0.0
+    # instances are independent and the splat is order-independent: views 8..15 alone reproduce the batch bit for bit
+    sub = dpc_amd.pointcloud_project_fast(cfg, pc[8:16].detach(), pose[8:16].detach(), None, None, kern,
+                                          scaling_factor=scale[8:16].detach())
+    assert float((sub["proj"] - proj[8:16]).abs().max()) == 0.0
+    # oracle on the first 8 views (their upstream gradient is that of the 8-view problem: recompute it there)
+    c8 = {k: (v[:8] if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+    _against_reference_cpu(c8, 8, chunk=4)
+
+
+def test_training_step_runs_and_learns():
+    """BASELINE configs[2]: the full chair_unsupervised step (stock PyTorch nets -> HIP projector with fused
+    point dropout -> HIP silhouette-loss epilogue with the min over 4 pose candidates -> Adam) on 1 GPU, at a
+    reduced model batch; the loss is finite, every parameter gets a gradient, and a few steps lower the loss."""
+    import os
+    import sys
+    ex = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "chair_unsupervised")
+    sys.path.insert(0, ex)
+    import train_step as ts
+    from nets import Im2PointCloud
+    dev = torch.device("cuda")
+    cfg = ts.make_cfg(batch_size=4, pc_point_dropout=0.5, pc_point_dropout_scheduled=False)
+    torch.manual_seed(0)
+    net = Im2PointCloud(cfg, 128).to(dev)
+    projector = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device=dev)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    inputs = ts.synthetic_batch(cfg, dev, 128, seed=0)
+    losses = [float(ts.train_step(net, projector, inputs, opt)) for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert projector._fused_dropout_ok(torch.empty(80, 8000, 3, device=dev), None)      # the fused draw was used
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
