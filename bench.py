@@ -111,9 +111,9 @@ def kernel_algorithmic_bytes(label, case, save_xy):
     if label == "points_fwd":
         return B * (N * 24 + 8 * N * 8)
     if label == "points_bwd":
-        return B * (N * 36 + 8 * N * 8)
-    if label == "zsort":
-        return B * N * 40
+        return B * N * 88          # partials 48 + pc 12 + tr_pc 12 + slot 4 read, dpc 12 written
+    if label in ("zsort", "zhist", "zscatter"):
+        return B * N * 44          # pc 12 read; tr_pc 12 + record 16 + slot 4 written (whole sort, either form)
     return 0
 
 
