@@ -500,7 +500,8 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
     // then the camera-transform VJP over the per-slot partials
     rc = launch_gather_yx(st, S, plan, tA, pi, clip_mask, taps_x, taps_y, parts);
     if (rc) return rc;
-    return launch_points_bwd_sorted(st, S, P, pc, pose, trans, focal, tr_pc, pi, dtr_pc_in, parts, dpc, dpose, dtrans,
+    return launch_points_bwd_sorted(st, S, P, pc, pose, trans, focal, tr_pc, pi, dtr_pc_in, parts,
+                                    plan.nstrips == 1 ? 2 : 4, dpc, dpose, dtrans,
                                     dfocal, scale ? dscale : nullptr, accum, (zfused && scale) ? dsparts : nullptr,
                                     nzb);
   }
