@@ -479,3 +479,32 @@ def knife_edge_inputs_match_reference_conventions(dev, D, Dz):
     # its gradient is not blocked by the clip
     k = len(nodes_xy + [0.1]) * 1 + 1                                   # (y = +0.5, x = +0.5)
     assert pts[k] == (-0.125, 0.5, 0.5) and np.abs(rgpc[k]).max() > 0 and np.abs(gpc[k]).max() > 0
+
+
+def deep_grid_takes_the_generic_path(dev, D=32, Dz=320, K=5, sigma=0.9):
+    """vox_size_z > 256: the plane-occupancy words of the fused path cover 256 planes, deeper grids must take
+    the generic path (round-1 review: the fused path silently dropped planes >= 256).  Forward and gradients
+    against the NumPy oracle."""
+    import ctypes
+    B, N = 2, 300
+    inp = synth.make_inputs(B, N, 777)
+    inp = _nudge_off_cell_faces(inp, None, None, Dz, D)
+    cfg = dpc_amd.default_config(vox_size=D, vox_size_z=Dz, pc_gauss_kernel_size=K)
+    taps = onp.smoothing_taps(D, Dz, K, sigma)
+    lib = dpc_amd.get_library()
+    S = dpc_amd._capi.DpcShape(B, N, Dz, D, K, K, len(taps[2]))
+    P = dpc_amd._capi.DpcParams(2.0, 1.875, 1e-5, 10.0, 1, 0, 0, 0, 0)
+    assert lib.dpc_saved_layout(ctypes.byref(S), ctypes.byref(P)) == 1
+    t = lambda a: torch.tensor(a, device=dev, requires_grad=True)
+    pc, pose, scale = t(inp["pc"]), t(inp["pose"]), t(inp["scale"])
+    out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, dpc_amd.smoothing_kernel(cfg, sigma, device=dev),
+                                          scaling_factor=scale)
+    w = np.random.default_rng(4).standard_normal(tuple(out["proj"].shape))
+    g = torch.autograd.grad(out["proj"], [pc, pose, scale], torch.tensor(w, dtype=torch.float32, device=dev))
+    f64 = lambda a: a.astype(np.float64)
+    fw = onp.project_forward(f64(inp["pc"]), f64(inp["pose"]), None, f64(inp["scale"]), None, taps, Dz=Dz, D=D)
+    bw = onp.project_backward(f64(inp["pc"]), f64(inp["pose"]), None, f64(inp["scale"]), None, taps, fw, dproj=w)
+    assert maxabs(out["proj"].detach().cpu().numpy(), fw["proj"]) < TOL_PROJ
+    assert relerr(g[0].cpu().numpy(), bw["dpc"]) < TOL_GRAD
+    assert relerr(g[1].cpu().numpy(), bw["dpose"]) < TOL_GRAD
+    assert relerr(g[2].cpu().numpy(), bw["dscale"].reshape(g[2].shape)) < TOL_GRAD

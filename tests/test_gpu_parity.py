@@ -304,6 +304,10 @@ def test_knife_edges_without_nudging(D, Dz):
     parity_cases.knife_edge_inputs_match_reference_conventions("cuda", D, Dz)
 
 
+def test_deep_grid_takes_the_generic_path():
+    parity_cases.deep_grid_takes_the_generic_path("cuda")
+
+
 def _against_reference_cpu(c, B, dev="cuda", chunk=None):
     """HIP fwd+bwd on B views of a synthetic config against oracle/reference_cpu.py (fp64) on the SAME views.
     The function is only piecewise smooth (cell faces, the clip at G0 = 1): with ~10^5 points a handful sit
