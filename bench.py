@@ -88,7 +88,7 @@ def build_train_case(args, device, rank, world):
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[device.index], bucket_cap_mb=64,
                                                           gradient_as_bucket_view=True)
     projector = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device=device)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=bool(args.graph))
     inputs = ts.synthetic_batch(cfg, device, 128, seed=rank)
     views = cfg.batch_size * cfg.step_size * cfg.pose_predict_num_candidates
     case = dict(B=views, N=int(cfg.pc_num_points * args.keep_prob), D=cfg.vox_size, K=cfg.pc_gauss_kernel_size,
@@ -245,6 +245,25 @@ def main():
     else:
         case = build_case(args.config, args.batch, device, seed_offset=1000 * rank, kind=args.points, N=args.num_points)
         run = lambda: step(case)
+    if args.graph and train:
+        # The training step is ~420 launches (stock PyTorch layers, optimiser, the projector's 10 kernels): eager,
+        # the host sets the pace.  The whole step -- nets, projector, loss epilogue, backward, Adam -- is recorded
+        # into ONE hipGraph (the library only enqueues on the stream it is handed) and replayed.
+        if world > 1:
+            raise SystemExit("--graph with --config 3 is single-GPU (DDP's bucketed all-reduce is not captured here)")
+        if args.keep_prob != 1.0:
+            raise SystemExit("--graph with --config 3 needs --keep-prob 1: the fused dropout's per-step seed is a "
+                             "host-side argument and would be frozen into the graph")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):                     # allocator, MIOpen solver search, Adam state
+                case["run"]()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            case["graph_loss"] = case["run"]()
+        run = graph.replay
     if args.graph and not train:
         # the library only enqueues on the stream it is handed, so a whole step (forward, loss
         # gradient, backward) records into one hipGraph; replay costs one launch on the host
@@ -290,7 +309,7 @@ def main():
     if not DRY_RUN:                         # every rank steps (DDP's all-reduce needs them all); rank 0 records
         if rank == 0:
             lib.profile(True)
-        for _ in range(psteps):
+        for _ in range(psteps):                 # (eager also in --graph mode: the per-kernel events need real launches)
             case["run"]() if train else step(case)
         torch.cuda.synchronize()
     if rank == 0 and not DRY_RUN:

@@ -40,7 +40,9 @@ def quaternion_multiply(a, b):
 
 
 def quaternion_conjugate(q):
-    return q * q.new_tensor([1.0, -1.0, -1.0, -1.0])
+    # (no constant tensor from a Python list here: that is a synchronous host-to-device copy on every call,
+    #  and not capturable into a HIP graph)
+    return torch.cat([q[..., :1], -q[..., 1:]], dim=-1)
 
 
 def quaternion_normalise(q):

@@ -508,3 +508,45 @@ def deep_grid_takes_the_generic_path(dev, D=32, Dz=320, K=5, sigma=0.9):
     assert relerr(g[0].cpu().numpy(), bw["dpc"]) < TOL_GRAD
     assert relerr(g[1].cpu().numpy(), bw["dpose"]) < TOL_GRAD
     assert relerr(g[2].cpu().numpy(), bw["dscale"].reshape(g[2].shape)) < TOL_GRAD
+
+
+def degenerate_clouds_against_numpy_oracle(dev, heavy=True):
+    """Clouds that stress the bucket logic of the fused path: a single point; every point outside the cube; every
+    point in ONE depth plane (far more than 2 x 256 points in a plane: the re-read loops; with `heavy` more than
+    4096: the float-atomic fallback of the splat); all points on one spot (a pile-up far above 1: clipped, gradient
+    blocked at that cell)."""
+    D, K, sigma = 64, 5, 0.9
+    cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K)
+    kern = dpc_amd.smoothing_kernel(cfg, sigma, device=dev)
+    taps = onp.smoothing_taps(D, -1, K, sigma)
+    rng = np.random.default_rng(11)
+    quat = np.array([[1.0, 0.0, 0.0, 0.0]], np.float32)
+    nsheet = 6000 if heavy else 700
+    sheet = np.stack([np.full(nsheet, 0.1003), rng.uniform(-0.3, 0.3, nsheet), rng.uniform(-0.3, 0.3, nsheet)], -1)
+    clouds = {
+        "single": np.array([[0.05, -0.11, 0.2]]),
+        "all_outside": rng.uniform(0.8, 0.9, (50, 3)),
+        "sheet": sheet,
+        "pile": np.tile(np.array([[0.013, 0.021, -0.034]]), (300, 1)),
+    }
+    for name, pts in clouds.items():
+        pc_np = pts.astype(np.float32)[None]
+        inp = {"pc": pc_np, "pose": quat}
+        if name in ("sheet", "single"):
+            inp = _nudge_off_cell_faces(inp, None, None, D, D)
+        pc = torch.tensor(inp["pc"], device=dev, requires_grad=True)
+        pose = torch.tensor(quat, device=dev, requires_grad=True)
+        out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern)
+        w = rng.standard_normal(tuple(out["proj"].shape))
+        g = torch.autograd.grad(out["proj"], [pc, pose], torch.tensor(w, dtype=torch.float32, device=dev))
+        f64 = lambda a: a.astype(np.float64)
+        fw = onp.project_forward(f64(inp["pc"]), f64(quat), None, None, None, taps, Dz=D, D=D)
+        bw = onp.project_backward(f64(inp["pc"]), f64(quat), None, None, None, taps, fw, dproj=w)
+        assert maxabs(out["proj"].detach().cpu().numpy(), fw["proj"]) < TOL_PROJ, name
+        scale_ = max(float(np.abs(bw["dpc"]).max()), 1e-12)
+        assert maxabs(g[0].cpu().numpy(), bw["dpc"]) <= TOL_GRAD * scale_ + 1e-9, name
+        if name == "all_outside":
+            assert float(g[0].abs().max()) == 0.0 and float(g[1].abs().max()) == 0.0
+            assert abs(float(out["proj"].max()) - float(out["proj"].min())) == 0.0       # every ray is the empty ray
+        if name == "pile":
+            assert float(g[0].abs().max()) == 0.0       # G0 = 300 x weight >> 1 at all 8 corners: the clip blocks everything

@@ -304,6 +304,10 @@ def test_knife_edges_without_nudging(D, Dz):
     parity_cases.knife_edge_inputs_match_reference_conventions("cuda", D, Dz)
 
 
+def test_degenerate_clouds():
+    parity_cases.degenerate_clouds_against_numpy_oracle("cuda", heavy=True)
+
+
 def test_deep_grid_takes_the_generic_path():
     parity_cases.deep_grid_takes_the_generic_path("cuda")
 

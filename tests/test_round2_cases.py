@@ -38,6 +38,10 @@ def test_emu_deep_grid_takes_the_generic_path(emu):
     parity_cases.deep_grid_takes_the_generic_path("cpu", D=32, Dz=288)
 
 
+def test_emu_degenerate_clouds(emu):
+    parity_cases.degenerate_clouds_against_numpy_oracle("cpu", heavy=False)
+
+
 def test_dropout_reference_permutation_properties():
     from oracle import dropout_ref
     for N in (7, 64, 1000, 8000):
