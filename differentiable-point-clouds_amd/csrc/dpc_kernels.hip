@@ -357,6 +357,9 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   if (drc && !ray_sums) return DPC_E_NULL;
   const SplatPlan plan = splat_plan(S);
   if (plan.ok ? (!clip_mask || !point_index) : !grid_raw) return DPC_E_NULL;
+  if (plan.ok && ((uintptr_t)point_index & 15) != 0) return DPC_E_WORKSPACE;   // 16-byte point records
+  // the fused dropout lives in the depth sort of the fused path: refuse rather than silently keep every point
+  if (!plan.ok && P.dropout_keep > 0 && P.dropout_keep < S.N) return DPC_E_MODE;
   const bool plane = S.Kx > 0 || S.Ky > 0;
   if (plane && (!workspace || workspace_bytes < dpc_workspace_bytes(shape, 0) ||
                 ((uintptr_t)workspace & 255) != 0))
@@ -452,6 +455,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   const SplatPlan plan = splat_plan(S);
   const bool use_cmask = plan.ok;
   if (use_cmask ? (!clip_mask || !point_index) : !grid_raw) return DPC_E_NULL;
+  if (use_cmask && ((uintptr_t)point_index & 15) != 0) return DPC_E_WORKSPACE;
   if (!workspace || workspace_bytes < dpc_workspace_bytes(shape, 1) || ((uintptr_t)workspace & 255) != 0)
     return DPC_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;

@@ -64,7 +64,8 @@ typedef struct DpcParams {
   /* fused point dropout (dpc/util/point_cloud.py:293-319): keep exactly `dropout_keep` of the N
    * points of every instance, drawn without replacement, independently per instance, from the keyed
    * permutation of (dropout_seed, instance); 0 or >= N = keep everything.  Only the fused path
-   * (dpc_saved_layout bit 1) honours it; dropped points get a zero gradient. */
+   * (dpc_saved_layout bit 1) honours it -- other shapes return DPC_E_MODE; dropped points get a zero
+   * gradient. */
   int32_t dropout_keep;
   uint32_t dropout_seed;
 } DpcParams;

@@ -73,6 +73,16 @@ def test_c_abi_argument_validation_without_gpu():
     assert lib.dpc_silhouette_loss_fwd(null, 8, 4, 8, 4, *([null] * 7)) == -2     # GT smaller than the prediction
     assert lib.dpc_silhouette_loss_fwd(null, 8, 4, 8, 8, *([null] * 7)) == -1
     assert lib.dpc_silhouette_loss_bwd(null, 8, 4, 8, 8, *([null] * 5)) == -1
+    # the fused dropout is refused (not silently ignored) off the fused path; point_index must be 16-byte aligned
+    one = ctypes.c_void_p(256)
+    Pd = _capi.DpcParams(2.0, 1.875, 1e-5, 10.0, 1, 0, 0, 3, 7)
+    rc = lib.dpc_project_forward(null, ctypes.byref(_capi.DpcShape(1, 10, 20, 20, 5, 5, 5)), ctypes.byref(Pd), one, one, null,
+                                 null, null, one, one, one, one, one, null, null, one, one, one, null, one, 10 ** 9)
+    assert rc == -5                                      # DPC_E_MODE
+    rc = lib.dpc_project_forward(null, ctypes.byref(_capi.DpcShape(1, 10, 32, 32, 5, 5, 5)), ctypes.byref(P), one, one, null,
+                                 null, null, one, one, one, one, null, one, ctypes.c_void_p(260), one, one, one, null, one,
+                                 10 ** 9)
+    assert rc == -4                                      # DPC_E_WORKSPACE (misaligned point_index)
     with pytest.raises(_capi.DpcError):
         lib.check(-4, "x")
 
