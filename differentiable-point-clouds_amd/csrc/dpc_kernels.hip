@@ -224,7 +224,7 @@ int dpc_transform_bwd(dpc_stream_t stream, const DpcShape* shape, const DpcParam
   if (!params || !pc || !pose || !dtr_pc || !dpc || !dpose || !scratch) return DPC_E_NULL;
   if (!params->pose_is_quaternion && trans) return DPC_E_MODE;
   return launch_points_bwd((hipStream_t)stream, *shape, *params, pc, pose, trans, focal, nullptr, nullptr,
-                           nullptr, nullptr, nullptr, dtr_pc, nullptr, false, dpc, dpose, dtrans, dfocal, nullptr,
+                           nullptr, nullptr, dtr_pc, false, dpc, dpose, dtrans, dfocal, nullptr,
                            scratch, true);
 }
 
@@ -517,7 +517,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
     dg = tB;
   }
   // 3. sparse x-blur + clip mask + gather + transform VJP + reductions
-  return launch_points_bwd(st, S, P, pc, pose, trans, focal, tr_pc, dg, grid_raw, nullptr, taps_x, dtr_pc_in, nullptr,
+  return launch_points_bwd(st, S, P, pc, pose, trans, focal, tr_pc, dg, grid_raw, taps_x, dtr_pc_in,
                            true, dpc, dpose, dtrans, dfocal, scale ? dscale : nullptr, accum, false,
                            (zfused && scale) ? dsparts : nullptr, nzb);
 }
