@@ -4,8 +4,8 @@ points an instance keeps and compare the fused path with the projector run on th
 
 Reference semantics being reproduced (dpc/util/point_cloud.py:293-319): every instance keeps
 int(N * keep_prob) of its N points, drawn without replacement, independently of the other instances.
-The reference draws with np.random.choice inside a tf.py_func; here the draw is a 4-round Feistel permutation
-of [0, N) keyed by (seed, instance) and point n survives iff its image is < keep.
+The reference draws with np.random.choice inside a tf.py_func; here the draw is a 4-round unbalanced Feistel permutation
+of [0, N) (over ceil(log2 N) bits, cycle-walked) keyed by (seed, instance) and point n survives iff its image is < keep.
 
 Only tests/ import this module.
 """
@@ -26,20 +26,22 @@ def _mix32(x):
 
 def dropout_rank(N, seed, b):
     """pi_b(n) for n = 0..N-1 (uint64 array): a permutation of [0, N)."""
-    half = 1
-    while (1 << (2 * half)) < N:
-        half += 1
-    mask = np.uint64((1 << half) - 1)
+    k = 1
+    while (1 << k) < N:
+        k += 1
+    wl, wr = k // 2, k - k // 2
     key = _mix32(np.array([(int(seed) ^ ((b * 0x9E3779B9 + 0x7F4A7C15) & 0xFFFFFFFF)) & 0xFFFFFFFF], np.uint64))[0]
     x = np.arange(N, dtype=np.uint64)
     todo = np.ones(N, dtype=bool)
     while todo.any():
         xs = x[todo]
-        L, R = xs >> np.uint64(half), xs & mask
+        L, R = xs >> np.uint64(wr), xs & np.uint64((1 << wr) - 1)
+        a, c = wl, wr
         for r in range(4):
-            F = _mix32((R + key + np.uint64((r * 0x632BE5AB) & 0xFFFFFFFF)) & _M) & mask
+            F = _mix32((R + key + np.uint64((r * 0x632BE5AB) & 0xFFFFFFFF)) & _M) & np.uint64((1 << a) - 1)
             L, R = R, L ^ F
-        xs = (L << np.uint64(half)) | R
+            a, c = c, a
+        xs = (L << np.uint64(wr)) | R
         x[todo] = xs
         todo[todo] = xs >= np.uint64(N)
     return x
