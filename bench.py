@@ -91,6 +91,8 @@ def build_train_case(args, device, rank, world):
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=bool(args.graph))
     inputs = ts.synthetic_batch(cfg, device, 128, seed=rank)
     views = cfg.batch_size * cfg.step_size * cfg.pose_predict_num_candidates
+    if args.graph:
+        projector.enable_graph_replay()        # blur taps and the dropout's {keep, seed} at fixed device addresses
     case = dict(B=views, N=int(cfg.pc_num_points * args.keep_prob), D=cfg.vox_size, K=cfg.pc_gauss_kernel_size,
                 sigma=cfg.pc_relative_sigma, models=models, params=sum(p.numel() for p in net.parameters()),
                 run=lambda: ts.train_step(model, projector, inputs, opt, world))
@@ -251,9 +253,6 @@ def main():
         # into ONE hipGraph (the library only enqueues on the stream it is handed) and replayed.
         if world > 1:
             raise SystemExit("--graph with --config 3 is single-GPU (DDP's bucketed all-reduce is not captured here)")
-        if args.keep_prob != 1.0:
-            raise SystemExit("--graph with --config 3 needs --keep-prob 1: the fused dropout's per-step seed is a "
-                             "host-side argument and would be frozen into the graph")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -36,7 +36,8 @@ class DpcParams(ctypes.Structure):
     _fields_ = [("camera_distance", ctypes.c_float), ("focal_length", ctypes.c_float),
                 ("eps", ctypes.c_float), ("max_depth", ctypes.c_float),
                 ("pose_is_quaternion", ctypes.c_int32), ("collapse_mode", ctypes.c_int32),
-                ("flags", ctypes.c_int32), ("dropout_keep", ctypes.c_int32), ("dropout_seed", ctypes.c_uint32)]
+                ("flags", ctypes.c_int32), ("dropout_keep", ctypes.c_int32), ("dropout_seed", ctypes.c_uint32),
+                ("dropout_state", ctypes.c_void_p)]
 
 
 _P = ctypes.c_void_p

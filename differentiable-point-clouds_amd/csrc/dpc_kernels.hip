@@ -359,7 +359,7 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   if (plan.ok ? (!clip_mask || !point_index) : !grid_raw) return DPC_E_NULL;
   if (plan.ok && ((uintptr_t)point_index & 15) != 0) return DPC_E_WORKSPACE;   // 16-byte point records
   // the fused dropout lives in the depth sort of the fused path: refuse rather than silently keep every point
-  if (!plan.ok && P.dropout_keep > 0 && P.dropout_keep < S.N) return DPC_E_MODE;
+  if (!plan.ok && (P.dropout_state || (P.dropout_keep > 0 && P.dropout_keep < S.N))) return DPC_E_MODE;
   const bool plane = S.Kx > 0 || S.Ky > 0;
   if (plane && (!workspace || workspace_bytes < dpc_workspace_bytes(shape, 0) ||
                 ((uintptr_t)workspace & 255) != 0))

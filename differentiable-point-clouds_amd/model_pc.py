@@ -69,7 +69,13 @@ class ModelPointCloud(object):
         cfg = self.cfg()
         self._sigma_rel = get_smooth_sigma(cfg, self._global_step)
         self._gauss_sigma = self._sigma_rel / cfg.vox_size
-        self._gauss_kernel = smoothing_kernel(cfg, self._sigma_rel, device=self._device)
+        kernel = smoothing_kernel(cfg, self._sigma_rel, device=self._device)
+        if getattr(self, "_graph_replay", False):
+            # a recorded step holds the ADDRESSES of the filter taps: new values go into the same buffers
+            for old, new in zip(self._gauss_kernel, kernel):
+                old.copy_(new)
+        else:
+            self._gauss_kernel = kernel
 
     def setup_misc(self, generator=None):                     # model_pc.py:161-168
         """Reference cloud of the pose_student_align_loss: 2000 points ~ N(0,1) clipped to +-3
@@ -81,6 +87,38 @@ class ModelPointCloud(object):
     def set_global_step(self, global_step):
         self._global_step = global_step
         self.setup_sigma()
+        if getattr(self, "_graph_replay", False):
+            self._refresh_dropout_keep()
+
+    def enable_graph_replay(self):
+        """Make everything that changes from step to step live in device memory at fixed addresses, so that a
+        training step recorded ONCE into a HIP graph (torch.cuda.graph) stays right when replayed: the blur taps
+        are updated in place by set_global_step, and the fused dropout reads {keep, seed} from a device tensor --
+        `keep` follows the schedule through set_global_step (a fill_, enqueued between replays), `seed` is advanced
+        by a few integer launches that are part of the recorded step.  Call before capturing; then per step:
+        set_global_step(step); graph.replay()."""
+        if self._device is None or torch.device(self._device).type != "cuda":
+            raise ValueError("graph replay needs the projector on a ROCm device")
+        self._graph_replay = True
+        seed = (torch.initial_seed() * 1103515245 + 12345) & 0x7fffffff
+        self._dropout_seed64 = torch.tensor([seed], dtype=torch.int64, device=self._device)
+        self._dropout_state = torch.zeros(2, dtype=torch.int32, device=self._device)
+        self._dropout_state[1:2].copy_(self._dropout_seed64)
+        self._refresh_dropout_keep()
+
+    def _refresh_dropout_keep(self):
+        cfg = self.cfg()
+        keep = cfg.pc_num_points
+        if cfg.pc_point_dropout != 1:
+            keep = int(cfg.pc_num_points * float(self.get_dropout_keep_prob()))
+        self._dropout_state[0:1].fill_(keep)          # the scalar travels as a kernel argument: no host buffer to race on
+
+    def _advance_dropout_state(self):
+        """seed <- (seed * 1103515245 + 12345) mod 2^31 on the device (int64 arithmetic, no overflow)."""
+        s = self._dropout_seed64
+        s.mul_(1103515245).add_(12345).bitwise_and_(0x7fffffff)
+        self._dropout_state[1:2].copy_(s)
+        return self._dropout_state
 
     def gauss_sigma(self):
         return self._gauss_sigma
@@ -159,7 +197,10 @@ class ModelPointCloud(object):
             keep_prob = self.get_dropout_keep_prob()
             if self._fused_dropout_ok(all_points, all_rgb):
                 # the draw happens inside the projector's depth sort (no [B,N',3] copy, no argsort)
-                point_dropout = (int(all_points.shape[1] * float(keep_prob)), self._next_dropout_seed())
+                if getattr(self, "_graph_replay", False):
+                    point_dropout = self._advance_dropout_state()
+                else:
+                    point_dropout = (int(all_points.shape[1] * float(keep_prob)), self._next_dropout_seed())
             else:
                 all_points, all_rgb = pc_point_dropout(all_points, all_rgb, keep_prob)
         if cfg.pc_fast:

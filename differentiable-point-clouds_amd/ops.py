@@ -14,8 +14,9 @@ from . import _capi
 from ._capi import DpcParams, DpcShape
 
 ProjMeta = collections.namedtuple(
-    "ProjMeta", "Dz D camera_distance focal_length eps max_depth pose_quaternion collapse_mode dropout_keep dropout_seed",
-    defaults=(0, 0))
+    "ProjMeta", "Dz D camera_distance focal_length eps max_depth pose_quaternion collapse_mode dropout_keep dropout_seed "
+                "dropout_state",
+    defaults=(0, 0, None))     # dropout_state: int32[2] tensor {keep, seed} read by the kernels at run time (hipGraph replays)
 
 
 # ---------------------------------------------------------------------------
@@ -64,7 +65,8 @@ def _shape(B, N, meta, K=(0, 0, 0)):
 def _params(meta):
     return DpcParams(float(meta.camera_distance), float(meta.focal_length), float(meta.eps),
                      float(meta.max_depth), 1 if meta.pose_quaternion else 0, int(meta.collapse_mode), 0,
-                     int(meta.dropout_keep), int(meta.dropout_seed) & 0xffffffff)
+                     int(meta.dropout_keep), int(meta.dropout_seed) & 0xffffffff,
+                     None if meta.dropout_state is None else meta.dropout_state.data_ptr())
 
 
 def _check_points(pc, pose, trans, scale, focal, meta):
@@ -158,7 +160,11 @@ class ProjectFused(torch.autograd.Function):
         tr_pc = new(B, N, 3)
         layout = lib.dpc_saved_layout(ctypes.byref(shape), ctypes.byref(params))
         lib.check(min(layout, 0), "dpc_saved_layout")
-        if 0 < meta.dropout_keep < N and not layout & 2:
+        if meta.dropout_state is not None:
+            st = meta.dropout_state
+            if st.dtype != torch.int32 or st.numel() != 2 or not st.is_contiguous() or st.device != pc.device:
+                raise ValueError("dropout state must be a contiguous int32 tensor {keep, seed} on the points' device")
+        if (0 < meta.dropout_keep < N or meta.dropout_state is not None) and not layout & 2:
             raise ValueError("fused point dropout needs the fused path (power-of-two vox_size in [32,256], kernel size "
                              "5/11/21, vox_size_z <= 256); use pc_point_dropout for this shape")
         grid_raw = new(B, Dz, D, D) if layout & 1 else None

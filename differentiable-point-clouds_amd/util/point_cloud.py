@@ -198,20 +198,26 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
     pc_point_dropout (point_cloud.py:293-319) into the projector: every instance keeps exactly
     ``num_keep`` of its N points, drawn without replacement from a permutation keyed by (seed,
     instance), inside the depth sort -- no [B,N',3] copy of the cloud, dropped points get a zero
-    gradient.  ``tr_pc`` then still holds all N transformed points."""
+    gradient.  ``tr_pc`` then still holds all N transformed points.  ``point_dropout=state`` with an
+    int32 tensor ``{num_keep, seed}`` on the points' device makes the kernels read the pair at run time:
+    a step recorded into a HIP graph then draws a new subset on every replay (the caller advances the
+    tensor with enqueued work, see ModelPointCloud)."""
     _drc._check_cfg(cfg)
     meta = _meta(cfg)
     if point_dropout is not None:
         if all_rgb is not None:
             raise NotImplementedError("fused point dropout with colour channels: use pc_point_dropout")
-        meta = meta._replace(dropout_keep=int(point_dropout[0]), dropout_seed=int(point_dropout[1]) & 0xffffffff)
+        if isinstance(point_dropout, torch.Tensor):
+            meta = meta._replace(dropout_state=point_dropout)
+        else:
+            meta = meta._replace(dropout_keep=int(point_dropout[0]), dropout_seed=int(point_dropout[1]) & 0xffffffff)
     tx, ty, tz = _flat_taps(cfg, kernel, point_cloud.device)
     proj, proj_depth, tr_pc = ops.ProjectFused.apply(point_cloud, transform, predicted_translation,
                                                      scaling_factor, focal_length, tx, ty, tz, meta)
     state = {}
 
     def make_voxels():
-        if point_dropout is not None and 0 < meta.dropout_keep < point_cloud.shape[1]:
+        if meta.dropout_state is not None or 0 < meta.dropout_keep < point_cloud.shape[1]:
             raise NotImplementedError("'voxels' / 'drc_probs' of a projection with fused point dropout "
                                       "(the stage-level kernels see all N points): use pc_point_dropout")
         if "voxels" not in state:

@@ -73,12 +73,20 @@ def main():
     ap.add_argument("--batch-size", type=int, default=16, help="models per GPU")
     ap.add_argument("--image-size", type=int, default=128)
     ap.add_argument("--keep-prob", type=float, default=1.0, help="point dropout keep probability (1 = all 8000 points)")
+    ap.add_argument("--scheduled", action="store_true",
+                    help="anneal the dropout keep probability (from --keep-prob to 1) and the blur sigma over --max-steps")
+    ap.add_argument("--max-steps", type=int, default=1000, help="length of the schedules (cfg.max_number_of_steps)")
+    ap.add_argument("--graph", action="store_true",
+                    help="record the whole step (nets, projector, loss, backward, Adam) into one HIP graph and replay it; "
+                         "the schedules and the dropout draw keep moving (ModelPointCloud.enable_graph_replay). 1 GPU.")
     args = ap.parse_args()
     dd = dpc_amd.distributed
     rank, world, device = dd.init("nccl")
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    cfg = make_cfg(batch_size=args.batch_size, pc_point_dropout=args.keep_prob, pc_point_dropout_scheduled=False)
+    cfg = make_cfg(batch_size=args.batch_size, pc_point_dropout=args.keep_prob,
+                   pc_point_dropout_scheduled=args.scheduled, max_number_of_steps=args.max_steps,
+                   **({} if args.scheduled else {"pc_relative_sigma_end": 3.0}))
     torch.manual_seed(0)
     net = Im2PointCloud(cfg, args.image_size).to(device)
     model = net
@@ -86,14 +94,37 @@ def main():
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[device.index], bucket_cap_mb=64,
                                                           gradient_as_bucket_view=True)
     projector = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device=device)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=args.graph)
     inputs = synthetic_batch(cfg, device, args.image_size, seed=rank)
+    run = lambda: train_step(model, projector, inputs, opt, world)
+    if args.graph:
+        if world > 1:
+            raise SystemExit("--graph is single-GPU (DDP's bucketed all-reduce is not captured here)")
+        projector.enable_graph_replay()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):                   # allocator, MIOpen solver search, Adam state
+                run()
+        torch.cuda.current_stream().wait_stream(side)
+        graph, static = torch.cuda.CUDAGraph(), {}
+        with torch.cuda.graph(graph):
+            static["loss"] = run()
+
+        def run():
+            graph.replay()
+            return static["loss"]
+    step = 0
     for _ in range(args.warmup):
-        train_step(model, projector, inputs, opt, world)
+        projector.set_global_step(step)          # sigma / dropout schedules (in place under --graph)
+        run()
+        step += 1
     dd.barrier(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = train_step(model, projector, inputs, opt, world)
+        projector.set_global_step(step)
+        loss = run()
+        step += 1
     dd.barrier(device)
     dt = dd.max_over_ranks(time.perf_counter() - t0, device)
     if rank == 0:
@@ -105,7 +136,8 @@ def main():
                           "config": {"models_per_gpu": cfg.batch_size, "views": cfg.step_size,
                                      "pose_candidates": cfg.pose_predict_num_candidates, "vox_size": cfg.vox_size,
                                      "K": cfg.pc_gauss_kernel_size, "points": int(cfg.pc_num_points * args.keep_prob),
-                                     "params": nparams, "loss": float(loss)}}))
+                                     "params": nparams, "loss": float(loss), "hip_graph": bool(args.graph),
+                                     "scheduled": bool(args.scheduled)}}))
     dd.finalize()
 
 

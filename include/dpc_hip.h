@@ -68,6 +68,11 @@ typedef struct DpcParams {
    * gradient. */
   int32_t dropout_keep;
   uint32_t dropout_seed;
+  /* nullable DEVICE pointer to {int32 keep, int32 seed}: when set, the sort kernels read the pair from
+   * there at run time instead of from the two fields above, so a step recorded into a hipGraph draws a
+   * fresh subset (and follows a keep-probability schedule) on every replay -- the caller advances the
+   * pair with its own enqueued work.  Same meaning of the values; same DPC_E_MODE rule. */
+  const int32_t* dropout_state;
 } DpcParams;
 
 const char* dpc_version(void);

@@ -429,6 +429,18 @@ def fused_dropout_equals_explicit_subset(dev, B=3, N=420, D=32, K=5, keep=137, s
     full = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale, point_dropout=(N, 1))
     plain = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale)
     assert float((full["proj"] - plain["proj"]).abs().max()) == 0.0
+    # {keep, seed} read from device memory at run time (what a recorded HIP graph replays): same draw, bit for bit
+    state = torch.tensor([keep, seed & 0x7fffffff], dtype=torch.int32, device=dev)
+    by_value = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale,
+                                               point_dropout=(keep, seed & 0x7fffffff))
+    by_state = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale,
+                                               point_dropout=state)
+    assert float((by_state["proj"] - by_value["proj"]).abs().max()) == 0.0
+    g2 = torch.autograd.grad(by_state["proj"], [pc], w)[0].cpu().numpy()
+    assert np.count_nonzero(np.abs(g2).sum(-1)) <= B * keep
+    state[0] = N                                             # the kernels follow the tensor, not a copy of it
+    again = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale, point_dropout=state)
+    assert float((again["proj"] - plain["proj"]).abs().max()) == 0.0
 
 
 def knife_edge_inputs_match_reference_conventions(dev, D, Dz):

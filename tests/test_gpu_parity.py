@@ -414,3 +414,67 @@ def test_training_step_runs_and_learns():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     assert projector._fused_dropout_ok(torch.empty(80, 8000, 3, device=dev), None)      # the fused draw was used
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_graph_replay_follows_the_dropout_and_sigma_schedules():
+    """The whole training step recorded ONCE into a HIP graph (ModelPointCloud.enable_graph_replay): on every replay
+    the fused dropout draws a new subset from the {keep, seed} pair in device memory, `keep` and the blur taps follow
+    their schedules through set_global_step, and the projection inside the graph equals, bit for bit, an eager
+    call on the same points with that (keep, seed) by value."""
+    import os
+    import sys
+    ex = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "chair_unsupervised")
+    sys.path.insert(0, ex)
+    import train_step as ts
+    from nets import Im2PointCloud
+    dev = torch.device("cuda")
+    cfg = ts.make_cfg(batch_size=2, pc_point_dropout=0.07, pc_point_dropout_scheduled=True, max_number_of_steps=100)
+    torch.manual_seed(0)
+    net = Im2PointCloud(cfg, 128).to(dev)
+    projector = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device=dev)
+    projector.enable_graph_replay()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=True)
+    inputs = ts.synthetic_batch(cfg, dev, 128, seed=0)
+    static = {}
+
+    def run():
+        outputs = net(inputs["images"])
+        outputs = projector.replicate_outputs(outputs)
+        outputs = projector.compute_projection(inputs, outputs, is_training=True)
+        loss = projector.add_proj_loss(inputs, outputs, cfg.proj_weight)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        static.update(outputs=outputs, loss=loss.detach())
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            run()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run()
+    seeds, losses = [], []
+    for step in (0, 1, 2, 40, 80, 100):
+        projector.set_global_step(step)
+        graph.replay()
+        keep, seed = (int(v) for v in projector._dropout_state.tolist())
+        want_keep = int(cfg.pc_num_points * dpc_amd.model_pc.get_dropout_prob(cfg, step))
+        assert keep == want_keep, (step, keep, want_keep)
+        seeds.append(seed)
+        losses.append(float(static["loss"]))
+        o = static["outputs"]
+        kern = dpc_amd.smoothing_kernel(cfg, dpc_amd.model_pc.get_smooth_sigma(cfg, step), device=dev)
+        for a, b in zip(kern, projector.gauss_kernel()):
+            assert torch.equal(a, b)                                      # the taps moved in place
+        eager = dpc_amd.pointcloud_project_fast(cfg, o["all_points"].detach(), o["poses"].detach(), None, None, kern,
+                                                scaling_factor=o["all_scaling_factors"].detach(),
+                                                point_dropout=(keep, seed))
+        # bit for bit while the integer splat applies; a plane holding >= 4096 of the (untrained, clustered) points
+        # takes the float-atomic splat, whose sum order varies from launch to launch
+        err = float((eager["proj"] - o["projs"].detach()).abs().max())
+        assert err == 0.0 if keep < 4096 else err < 2e-6, (step, keep, err)
+    assert len(set(seeds)) == len(seeds)                                  # a fresh draw per replay
+    assert all(np.isfinite(losses))
