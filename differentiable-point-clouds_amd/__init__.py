@@ -14,4 +14,4 @@ from .util.gauss_kernel import gauss_kernel_1d, smoothing_kernel  # noqa: F401
 from .util.point_cloud import (pc_perspective_transform, pc_point_dropout, pointcloud2voxels3d_fast,  # noqa: F401
                                pointcloud_project_fast, smoothen_voxels3d)
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

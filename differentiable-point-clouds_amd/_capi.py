@@ -47,6 +47,7 @@ _PP = ctypes.POINTER(DpcParams)
 # name -> (restype, argtypes); mirrors include/dpc_hip.h one to one
 SIGNATURES = {
     "dpc_version": (ctypes.c_char_p, []),
+    "dpc_abi_struct_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "dpc_workspace_bytes": (ctypes.c_size_t, [_SP, ctypes.c_int]),
     "dpc_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "dpc_profile_count": (ctypes.c_int, []),
@@ -98,6 +99,10 @@ class DpcLibrary(object):
             fn.restype = res
             fn.argtypes = args
             setattr(self, name, fn)
+        for which, mirror in ((0, DpcShape), (1, DpcParams)):          # a stale struct mirror must not get as far as a launch
+            if self.dpc_abi_struct_bytes(which) != ctypes.sizeof(mirror):
+                raise DpcError("%s: sizeof(%s) is %d in the library, %d in this binding (rebuild the library)"
+                               % (path, mirror.__name__, self.dpc_abi_struct_bytes(which), ctypes.sizeof(mirror)))
 
     def version(self):
         return self.dpc_version().decode()

@@ -137,7 +137,9 @@ static inline hipError_t dpc_memset(const char* label, void* p, size_t n, hipStr
 
 extern "C" {
 
-const char* dpc_version(void) { return "dpc_hip 0.1.0 (gfx950)"; }
+const char* dpc_version(void) { return "dpc_hip 0.2.0 (gfx950)"; }
+
+size_t dpc_abi_struct_bytes(int which) { return which == 0 ? sizeof(DpcShape) : which == 1 ? sizeof(DpcParams) : 0; }
 
 int dpc_profile_enable(int on) {
   dpcprof::clear();

@@ -77,6 +77,11 @@ typedef struct DpcParams {
 
 const char* dpc_version(void);
 
+/* sizeof(DpcShape) (which = 0) / sizeof(DpcParams) (which = 1) as THIS build lays them out, 0 for anything
+ * else: a binding (ctypes / cgo / JNI struct mirror) compares it with its own layout at load time instead
+ * of discovering a stale mirror through wrong results. */
+size_t dpc_abi_struct_bytes(int which);
+
 /* Optional per-kernel timing for benchmarking: while enabled, every kernel /
  * memset the library enqueues is bracketed by HIP events recorded on the launch
  * stream.  dpc_profile_get synchronises on record i and returns its label

@@ -38,6 +38,16 @@ def test_hip_library_loads_and_exports_every_declared_symbol():
     assert "gfx950" in lib.version() and not lib.host_memory
 
 
+def test_struct_mirrors_match_the_library_layout():
+    """The ctypes mirrors of DpcShape / DpcParams have the sizes the library was built with (the loader
+    refuses a mismatch), and the nullable device pointer added in round 2 sits where C puts it."""
+    lib = _capi.get_library()
+    assert lib.dpc_abi_struct_bytes(0) == ctypes.sizeof(_capi.DpcShape) == 28
+    assert lib.dpc_abi_struct_bytes(1) == ctypes.sizeof(_capi.DpcParams) == 48
+    assert lib.dpc_abi_struct_bytes(2) == 0
+    assert _capi.DpcParams.dropout_state.offset == 40
+
+
 def test_hip_library_contains_gfx950_code_object():
     blob = open(_capi.LIB_PATH, "rb").read()
     assert b"gfx950" in blob and b"k_zfwd" in blob and b"k_blur_plane" in blob
