@@ -198,6 +198,7 @@ static inline void dpc_pk_mul_tap(dpc_v2f& acc, dpc_v2f pair, dpc_v2f v) {
   acc = tt * v;
 }
 
+static inline void dpc_consume(float) {}
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only used on wave-uniform values
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
