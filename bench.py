@@ -62,16 +62,15 @@ def build_case(cfg_id, B, device, seed_offset=0, kind="shell", N=None):
                 kern=dpc_amd.smoothing_kernel(cfg, c["sigma"], device=device),
                 gt=torch.tensor(dpc_amd.synthetic.disk_gt(c["B"], c["D"]), device=device),
                 B=c["B"], N=c["N"], D=c["D"], K=c["K"], sigma=c["sigma"])
-    case["gt_neg_over_b"] = -case["gt"] / c["B"]        # constant input: -gt / B
     return case
 
 
 def step(case):
+    # forward with the L2 silhouette loss fused into the collapse kernel (model_pc.py:414-415 without pose
+    # candidates): dproj = (proj - gt) / B comes out of k_zfwd's registers; then the backward pass
     out = dpc_amd.pointcloud_project_fast(case["cfg"], case["pc"], case["pose"], None, None, case["kern"],
-                                          scaling_factor=case["scale"])
-    proj = out["proj"]
-    dproj = torch.add(case["gt_neg_over_b"], proj.detach(), alpha=1.0 / case["B"])   # (proj - gt) / B, one launch
-    return torch.autograd.grad(proj, [case["pc"], case["pose"], case["scale"]], dproj)
+                                          scaling_factor=case["scale"], l2_target=(case["gt"], 1.0 / case["B"]))
+    return torch.autograd.grad(out["proj"], [case["pc"], case["pose"], case["scale"]], out["proj_l2_grad"])
 
 
 def build_train_case(args, device, rank, world):

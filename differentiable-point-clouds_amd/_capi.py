@@ -37,7 +37,8 @@ class DpcParams(ctypes.Structure):
                 ("eps", ctypes.c_float), ("max_depth", ctypes.c_float),
                 ("pose_is_quaternion", ctypes.c_int32), ("collapse_mode", ctypes.c_int32),
                 ("flags", ctypes.c_int32), ("dropout_keep", ctypes.c_int32), ("dropout_seed", ctypes.c_uint32),
-                ("dropout_state", ctypes.c_void_p)]
+                ("dropout_state", ctypes.c_void_p), ("l2_target", ctypes.c_void_p), ("l2_grad", ctypes.c_void_p),
+                ("l2_weight", ctypes.c_float)]
 
 
 _P = ctypes.c_void_p

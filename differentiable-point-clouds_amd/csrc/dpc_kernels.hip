@@ -357,6 +357,8 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   const bool drc = P.collapse_mode == DPC_COLLAPSE_DRC;
   if (!drc && P.collapse_mode != DPC_COLLAPSE_MAX) return DPC_E_MODE;
   if (drc && !ray_sums) return DPC_E_NULL;
+  if (P.l2_target && !drc) return DPC_E_MODE;   // the L2 epilogue lives in the DRC collapse kernel
+  if (P.l2_target && !P.l2_grad) return DPC_E_NULL;
   const SplatPlan plan = splat_plan(S);
   if (plan.ok ? (!clip_mask || !point_index) : !grid_raw) return DPC_E_NULL;
   if (plan.ok && ((uintptr_t)point_index & 15) != 0) return DPC_E_WORKSPACE;   // 16-byte point records

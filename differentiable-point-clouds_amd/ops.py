@@ -15,8 +15,10 @@ from ._capi import DpcParams, DpcShape
 
 ProjMeta = collections.namedtuple(
     "ProjMeta", "Dz D camera_distance focal_length eps max_depth pose_quaternion collapse_mode dropout_keep dropout_seed "
-                "dropout_state",
-    defaults=(0, 0, None))     # dropout_state: int32[2] tensor {keep, seed} read by the kernels at run time (hipGraph replays)
+                "dropout_state l2_target l2_weight",
+    defaults=(0, 0, None, None, 0.0))
+# dropout_state: int32[2] tensor {keep, seed} read by the kernels at run time (hipGraph replays)
+# l2_target / l2_weight: [B,D,D(,1)] image and factor of the fused L2 loss epilogue (ProjectFused's 4th output)
 
 
 # ---------------------------------------------------------------------------
@@ -62,11 +64,13 @@ def _shape(B, N, meta, K=(0, 0, 0)):
     return DpcShape(int(B), int(N), int(meta.Dz), int(meta.D), int(K[0]), int(K[1]), int(K[2]))
 
 
-def _params(meta):
+def _params(meta, l2_grad=None):
     return DpcParams(float(meta.camera_distance), float(meta.focal_length), float(meta.eps),
                      float(meta.max_depth), 1 if meta.pose_quaternion else 0, int(meta.collapse_mode), 0,
                      int(meta.dropout_keep), int(meta.dropout_seed) & 0xffffffff,
-                     None if meta.dropout_state is None else meta.dropout_state.data_ptr())
+                     None if meta.dropout_state is None else meta.dropout_state.data_ptr(),
+                     None if l2_grad is None else meta.l2_target.data_ptr(),
+                     None if l2_grad is None else l2_grad.data_ptr(), float(meta.l2_weight))
 
 
 def _check_points(pc, pose, trans, scale, focal, meta):
@@ -145,7 +149,10 @@ class _Workspace(object):
 # ---------------------------------------------------------------------------
 class ProjectFused(torch.autograd.Function):
     """pointcloud_project_fast as ONE autograd node: (pc, pose, trans, scale,
-    focal) -> (proj [B,D,D,1], proj_depth [B,D,D,1] | None, tr_pc [B,N,3])."""
+    focal) -> (proj [B,D,D,1], proj_depth [B,D,D,1] | None, tr_pc [B,N,3], l2_grad [B,D,D,1] | None).
+    l2_grad (meta.l2_target set) = l2_weight * (proj - l2_target), written by the collapse kernel itself:
+    the gradient of 0.5 * l2_weight * sum((proj - target)^2) w.r.t. proj, ready to be passed back as
+    grad_outputs; not differentiable."""
 
     @staticmethod
     def forward(ctx, pc, pose, trans, scale, focal, tx, ty, tz, meta):
@@ -155,8 +162,18 @@ class ProjectFused(torch.autograd.Function):
         (tx, ty, tz), K = _taps_of((tx, ty, tz))
         B, N = pc.shape[0], pc.shape[1]
         Dz, D = meta.Dz, meta.D
-        shape, params = _shape(B, N, meta, K), _params(meta)
         new = lambda *s, **kw: _poison(torch.empty(*s, dtype=kw.get("dtype", torch.float32), device=pc.device))
+        l2_grad = None
+        if meta.l2_target is not None:
+            tgt = meta.l2_target
+            if meta.collapse_mode != _capi.DPC_COLLAPSE_DRC:
+                raise ValueError("the fused L2 epilogue lives in the DRC collapse kernel (ptn_max_projection is off it)")
+            _lib_for(pc, tgt)
+            if tgt.numel() != B * D * D or tuple(tgt.shape[:3]) != (B, D, D) or not tgt.is_contiguous():
+                raise ValueError("l2 target must be a contiguous [B,D,D] or [B,D,D,1] image, got %s for B=%d, D=%d"
+                                 % (tuple(tgt.shape), B, D))
+            l2_grad = new(B, D, D, 1)
+        shape, params = _shape(B, N, meta, K), _params(meta, l2_grad)
         tr_pc = new(B, N, 3)
         layout = lib.dpc_saved_layout(ctypes.byref(shape), ctypes.byref(params))
         lib.check(min(layout, 0), "dpc_saved_layout")
@@ -188,13 +205,15 @@ class ProjectFused(torch.autograd.Function):
         ctx.focal_shape = None if focal is None else tuple(focal.shape)
         ctx.save_for_backward(pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, grid_raw, clip_mask, point_index,
                               grid_blur, logt)
-        return proj, depth, tr_pc
+        if l2_grad is not None:
+            ctx.mark_non_differentiable(l2_grad)
+        return proj, depth, tr_pc, l2_grad
 
     @staticmethod
-    def backward(ctx, dproj, ddepth, dtr):
+    def backward(ctx, dproj, ddepth, dtr, _dl2=None):
         (pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, grid_raw, clip_mask, point_index, grid_blur,
          logt) = ctx.saved_tensors
-        meta = ctx.meta
+        meta = ctx.meta._replace(l2_target=None)
         lib = _lib_for(pc)
         B, N = pc.shape[0], pc.shape[1]
         shape, params = _shape(B, N, meta, ctx.K), _params(meta)

@@ -191,7 +191,8 @@ class ProjectionOutputs(dict):
 
 
 def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
-                            all_rgb, kernel=None, scaling_factor=None, focal_length=None, *, point_dropout=None):
+                            all_rgb, kernel=None, scaling_factor=None, focal_length=None, *, point_dropout=None,
+                            l2_target=None):
     """dpc/util/point_cloud.py:229-290.
 
     ``point_dropout=(num_keep, seed)`` (keyword-only, not in the reference signature) fuses
@@ -201,7 +202,13 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
     gradient.  ``tr_pc`` then still holds all N transformed points.  ``point_dropout=state`` with an
     int32 tensor ``{num_keep, seed}`` on the points' device makes the kernels read the pair at run time:
     a step recorded into a HIP graph then draws a new subset on every replay (the caller advances the
-    tensor with enqueued work, see ModelPointCloud)."""
+    tensor with enqueued work, see ModelPointCloud).
+
+    ``l2_target=(gt, weight)`` (keyword-only) is the silhouette L2 loss of model_pc.py:414-415 fused into
+    the collapse kernel: the result gains ``"proj_l2_grad"`` = weight * (proj - gt), the gradient of
+    0.5 * weight * sum((proj - gt)^2) w.r.t. ``proj`` -- pass it to backward as the gradient of ``proj``
+    (``torch.autograd.grad(out["proj"], inputs, out["proj_l2_grad"])``); gt is [B,D,D] or [B,D,D,1] at the
+    projection's own size."""
     _drc._check_cfg(cfg)
     meta = _meta(cfg)
     if point_dropout is not None:
@@ -211,9 +218,11 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
             meta = meta._replace(dropout_state=point_dropout)
         else:
             meta = meta._replace(dropout_keep=int(point_dropout[0]), dropout_seed=int(point_dropout[1]) & 0xffffffff)
+    if l2_target is not None:
+        meta = meta._replace(l2_target=l2_target[0].detach(), l2_weight=float(l2_target[1]))
     tx, ty, tz = _flat_taps(cfg, kernel, point_cloud.device)
-    proj, proj_depth, tr_pc = ops.ProjectFused.apply(point_cloud, transform, predicted_translation,
-                                                     scaling_factor, focal_length, tx, ty, tz, meta)
+    proj, proj_depth, tr_pc, l2_grad = ops.ProjectFused.apply(point_cloud, transform, predicted_translation,
+                                                              scaling_factor, focal_length, tx, ty, tz, meta)
     state = {}
 
     def make_voxels():
@@ -257,6 +266,8 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
         proj_rgb = None if probs is None else _drc.project_volume_rgb_integral(cfg, probs, voxels_rgb)
 
     eager = {"proj": proj, "tr_pc": tr_pc, "voxels_rgb": voxels_rgb, "proj_rgb": proj_rgb, "proj_depth": proj_depth}
+    if l2_target is not None:
+        eager["proj_l2_grad"] = l2_grad
     out = ProjectionOutputs(eager, make_voxels, make_probs)
     return out
 

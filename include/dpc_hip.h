@@ -73,6 +73,14 @@ typedef struct DpcParams {
    * fresh subset (and follows a keep-probability schedule) on every replay -- the caller advances the
    * pair with its own enqueued work.  Same meaning of the values; same DPC_E_MODE rule. */
   const int32_t* dropout_state;
+  /* fused L2 silhouette-loss epilogue (dpc/models/model_pc.py:414-415, the branch without pose candidates):
+   * when l2_target (device, [B,D,D], same layout as proj) is set, the collapse kernel also writes
+   * l2_grad[b,y,x] = l2_weight * (proj[b,y,x] - l2_target[b,y,x]) -- the loss gradient the backward call takes as
+   * dproj -- from the registers that hold proj: no extra pass over the images.  DRC collapse only
+   * (DPC_E_MODE otherwise); l2_grad must then be non-null (DPC_E_NULL). */
+  const float* l2_target;
+  float* l2_grad;
+  float l2_weight;
 } DpcParams;
 
 const char* dpc_version(void);

@@ -1,6 +1,7 @@
 """Parity checks shared by the CPU emulation tier (tests/test_emu_kernels.py,
 device "cpu" + emulation library) and the GPU tier (tests/test_gpu_parity.py,
 device "cuda" + libdpc_hip.so)."""
+import pytest
 import numpy as np
 import torch
 
@@ -441,6 +442,39 @@ def fused_dropout_equals_explicit_subset(dev, B=3, N=420, D=32, K=5, keep=137, s
     state[0] = N                                             # the kernels follow the tensor, not a copy of it
     again = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale, point_dropout=state)
     assert float((again["proj"] - plain["proj"]).abs().max()) == 0.0
+
+
+def fused_l2_epilogue_equals_the_autograd_loss(dev, B=3, N=300, D=32, K=5):
+    """pointcloud_project_fast(l2_target=(gt, w)): 'proj_l2_grad' is w * (proj - gt) exactly, and feeding it back
+    as the gradient of proj gives the same input gradients as autograd through 0.5 * w * sum((proj - gt)^2)
+    (model_pc.py:414-415: tf.nn.l2_loss(gt - pred) / num_samples, w = 1 / num_samples)."""
+    inp = synth.make_inputs(B, N, 77)
+    cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K)
+    kern = dpc_amd.smoothing_kernel(cfg, 0.9, device=dev)
+    t = lambda a: torch.tensor(a, device=dev, requires_grad=True)
+    pc, pose, scale = t(inp["pc"]), t(inp["pose"]), t(inp["scale"])
+    gt = torch.tensor(np.random.default_rng(3).uniform(0, 1, (B, D, D, 1)).astype(np.float32), device=dev)
+    w = 1.0 / B
+    out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale, l2_target=(gt, w))
+    assert not out["proj_l2_grad"].requires_grad
+    assert float((out["proj_l2_grad"] - (out["proj"].detach() - gt) * w).abs().max()) == 0.0
+    g = torch.autograd.grad(out["proj"], [pc, pose, scale], out["proj_l2_grad"])
+    plain = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale)
+    assert float((plain["proj"] - out["proj"]).abs().max()) <= 1e-6      # (the generic path's float atomics reorder)
+    loss = 0.5 * w * ((plain["proj"] - gt) ** 2).sum()
+    gr = torch.autograd.grad(loss, [pc, pose, scale])
+    for a, b in zip(g, gr):
+        assert relerr(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    # [B,D,D] target works as well; anything else is refused, and so is the max-projection collapse
+    out3 = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale,
+                                           l2_target=(gt.reshape(B, D, D), w))
+    assert float((out3["proj_l2_grad"] - out["proj_l2_grad"]).abs().max()) <= 1e-6
+    with pytest.raises(ValueError):
+        dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale,
+                                        l2_target=(gt[:, : D // 2], w))
+    cfg_max = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K, ptn_max_projection=True)
+    with pytest.raises(ValueError):
+        dpc_amd.pointcloud_project_fast(cfg_max, pc, pose, None, None, kern, scaling_factor=scale, l2_target=(gt, w))
 
 
 def knife_edge_inputs_match_reference_conventions(dev, D, Dz):

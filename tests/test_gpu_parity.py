@@ -293,6 +293,13 @@ def test_asymmetric_filters(D, K):
     parity_cases.asymmetric_filters_against_cpu_oracle("cuda", D, K)
 
 
+def test_fused_l2_epilogue():
+    parity_cases.fused_l2_epilogue_equals_the_autograd_loss("cuda")
+    parity_cases.fused_l2_epilogue_equals_the_autograd_loss("cuda", B=32, N=8000, D=128, K=11)    # cfg2 (what bench.py times)
+    parity_cases.fused_l2_epilogue_equals_the_autograd_loss("cuda", B=8, N=2000, D=64, K=21)
+    parity_cases.fused_l2_epilogue_equals_the_autograd_loss("cuda", B=2, N=500, D=20, K=5)        # generic path
+
+
 def test_fused_dropout():
     parity_cases.fused_dropout_equals_explicit_subset("cuda")
     parity_cases.fused_dropout_equals_explicit_subset("cuda", B=5, N=8000, D=64, K=21, keep=560, seed=77)

@@ -43,9 +43,10 @@ def test_struct_mirrors_match_the_library_layout():
     refuses a mismatch), and the nullable device pointer added in round 2 sits where C puts it."""
     lib = _capi.get_library()
     assert lib.dpc_abi_struct_bytes(0) == ctypes.sizeof(_capi.DpcShape) == 28
-    assert lib.dpc_abi_struct_bytes(1) == ctypes.sizeof(_capi.DpcParams) == 48
+    assert lib.dpc_abi_struct_bytes(1) == ctypes.sizeof(_capi.DpcParams) == 72
     assert lib.dpc_abi_struct_bytes(2) == 0
     assert _capi.DpcParams.dropout_state.offset == 40
+    assert (_capi.DpcParams.l2_target.offset, _capi.DpcParams.l2_grad.offset, _capi.DpcParams.l2_weight.offset) == (48, 56, 64)
 
 
 def test_hip_library_contains_gfx950_code_object():
@@ -93,6 +94,14 @@ def test_c_abi_argument_validation_without_gpu():
                                  null, null, one, one, one, one, null, one, ctypes.c_void_p(260), one, one, one, null, one,
                                  10 ** 9)
     assert rc == -4                                      # DPC_E_WORKSPACE (misaligned point_index)
+    # fused L2 epilogue: DRC collapse only, and it needs somewhere to write
+    Pl = _capi.DpcParams(2.0, 1.875, 1e-5, 10.0, 1, 1, 0, 0, 0, None, 256, 256, 1.0)      # max collapse + l2_target
+    fwd = lambda Pp: lib.dpc_project_forward(null, ctypes.byref(_capi.DpcShape(1, 10, 32, 32, 5, 5, 5)), ctypes.byref(Pp),
+                                             one, one, null, null, null, one, one, one, one, null, one, one, one, one,
+                                             one, null, one, 10 ** 9)
+    assert fwd(Pl) == -5                                 # DPC_E_MODE
+    Pl = _capi.DpcParams(2.0, 1.875, 1e-5, 10.0, 1, 0, 0, 0, 0, None, 256, None, 1.0)     # l2_target without l2_grad
+    assert fwd(Pl) == -1                                 # DPC_E_NULL
     with pytest.raises(_capi.DpcError):
         lib.check(-4, "x")
 
