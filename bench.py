@@ -79,21 +79,28 @@ def build_train_case(args, device, rank, world):
     import train_step as ts
     from nets import Im2PointCloud
     models = args.batch or 16
-    cfg = ts.make_cfg(batch_size=models, pc_point_dropout=args.keep_prob, pc_point_dropout_scheduled=False)
+    image, toy, net_kw = 128, {}, {}
+    if DRY_RUN:    # toy sizes for the launch / DDP / reporting logic on the CPU emulation tier (never a measurement)
+        models, image = 1, 32
+        toy = dict(vox_size=32, pc_gauss_kernel_size=5, pc_relative_sigma=0.9, pc_num_points=150, step_size=2,
+                   pose_predict_num_candidates=2)
+        net_kw = dict(f_dim=4, fc_dim=32, z_dim=32)
+    cfg = ts.make_cfg(batch_size=models, pc_point_dropout=args.keep_prob, pc_point_dropout_scheduled=False, **toy)
     torch.manual_seed(0)
-    net = Im2PointCloud(cfg, 128).to(device)
+    net = Im2PointCloud(cfg, image, **net_kw).to(device)
     model = net
     if world > 1:
-        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[device.index], bucket_cap_mb=64,
-                                                          gradient_as_bucket_view=True)
+        ddp_kw = dict(device_ids=[device.index]) if device.type == "cuda" else {}
+        model = torch.nn.parallel.DistributedDataParallel(net, bucket_cap_mb=64, gradient_as_bucket_view=True, **ddp_kw)
     projector = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device=device)
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=bool(args.graph))
-    inputs = ts.synthetic_batch(cfg, device, 128, seed=rank)
+    inputs = ts.synthetic_batch(cfg, device, image, seed=rank)
     views = cfg.batch_size * cfg.step_size * cfg.pose_predict_num_candidates
     if args.graph:
         projector.enable_graph_replay()        # blur taps and the dropout's {keep, seed} at fixed device addresses
     case = dict(B=views, N=int(cfg.pc_num_points * args.keep_prob), D=cfg.vox_size, K=cfg.pc_gauss_kernel_size,
                 sigma=cfg.pc_relative_sigma, models=models, params=sum(p.numel() for p in net.parameters()),
+                views_per_model=cfg.step_size, candidates=cfg.pose_predict_num_candidates,
                 run=lambda: ts.train_step(model, projector, inputs, opt, world))
     return case
 
@@ -232,7 +239,6 @@ def main():
         rank, world, device = dd.init("gloo", device=torch.device("cpu"))
         dpc_amd.synthetic.CONFIGS[args.config] = dict(B=2, N=150, D=32, K=5, sigma=0.9)
         args.steps, args.warmup, args.repeats, args.no_cpu_baseline = min(args.steps, 2), min(args.warmup, 1), 0, True
-        args.projector_only = True
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a ROCm GPU (the projector has no CPU fallback)")
@@ -349,9 +355,9 @@ def main():
         cfg_idx = {1: 0, 2: 1, 3: 2 if world == 1 else 3, 5: 4}[args.config]
         if train:
             workload = ("BASELINE.json configs[%d]: chair_unsupervised training step (encoder+decoder+pose nets, stock "
-                        "PyTorch; HIP projector + silhouette-loss epilogue; Adam), %d models x 5 views x 4 pose "
+                        "PyTorch; HIP projector + silhouette-loss epilogue; Adam), %d models x %d views x %d pose "
                         "candidates = %d views per GPU of N=%d pts -> %d^3, K=%d, sigma=%.1f, %.1f M parameters%s"
-                        % (cfg_idx, case["models"], case["B"], case["N"], case["D"], case["K"], case["sigma"],
+                        % (cfg_idx, case["models"], case["views_per_model"], case["candidates"], case["B"], case["N"], case["D"], case["K"], case["sigma"],
                            case["params"] / 1e6, ", DDP (RCCL all-reduce)" if world > 1 else ""))
         else:
             workload = ("BASELINE.json configs[%d]%s: pointcloud_project_fast fwd+bwd, N=%d, grid %d^3, K=%d, sigma=%.1f, "

@@ -39,6 +39,17 @@ def test_gpus_2_self_launches_and_prints_one_line(emu_library):
     assert "cpu_baseline" not in j                   # rank 0 at N = 1 only
 
 
+def test_config_3_ddp_training_step_self_launches(emu_library):
+    """BASELINE configs[3]: `bench.py --gpus 2 --config 3` = the training step under DistributedDataParallel, one
+    rank per GPU (here: gloo ranks on the emulation tier at toy sizes), fused point dropout on; one JSON line."""
+    r = _run(["--gpus", "2", "--config", "3", "--steps", "2", "--warmup", "1", "--keep-prob", "0.5"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["training_step"] is True
+    assert "DDP" in j["config"]["parallelism"] and j["config"]["global_batch"] == 2 * j["config"]["global_batch"] // 2
+    assert j["value"] > 0 and j["steps_per_s"] > 0
+
+
 def test_gpus_1_runs_in_process(emu_library):
     r = _run(["--steps", "2", "--warmup", "1"])
     assert r.returncode == 0, r.stderr[-2000:]
