@@ -72,6 +72,7 @@ SIGNATURES = {
     "dpc_max_collapse_bwd": (ctypes.c_int, [_P, _SP, _P, _P, _P, ctypes.c_int]),
     "dpc_silhouette_loss_fwd": (ctypes.c_int, [_P] + [ctypes.c_int] * 4 + [_P] * 7),
     "dpc_silhouette_loss_bwd": (ctypes.c_int, [_P] + [ctypes.c_int] * 4 + [_P] * 5),
+    "dpc_student_loss": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, ctypes.c_float, _P, _P]),
     "dpc_point_index_ints": (ctypes.c_size_t, [_SP]),
     "dpc_nn_distance": (ctypes.c_int, [_P] + [ctypes.c_int] * 3 + [_P] * 5),
     "dpc_gauss_voxelize_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),

@@ -546,6 +546,15 @@ int dpc_silhouette_loss_bwd(dpc_stream_t stream, int B, int C, int D, int S, con
   return last_error();
 }
 
+int dpc_student_loss(dpc_stream_t stream, int n, int C, const float* poses, const int64_t* winners,
+                     const float* student, const float* weights, float scale, float* loss, float* dstudent) {
+  if (n <= 0 || C <= 0) return DPC_E_SHAPE;
+  if (!poses || !winners || !student || !loss || !dstudent) return DPC_E_NULL;
+  DPC_LAUNCH("student_loss", (k_student_loss), dim3(1, 1, 1), dim3(DPC_BLOCK, 1, 1), 0, (hipStream_t)stream, poses,
+             (const long long*)winners, student, weights, n, C, scale, loss, dstudent);
+  return last_error();
+}
+
 int dpc_nn_distance(dpc_stream_t stream, int dtype_bytes, int ns, int nt, const void* vs, const void* vt, void* proj,
                     void* min_dist, int32_t* idx) {
   if (ns <= 0 || nt <= 0) return DPC_E_SHAPE;

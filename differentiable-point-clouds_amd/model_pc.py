@@ -19,9 +19,6 @@ from .util.gauss_kernel import gauss_smoothen_image, smoothing_kernel
 from .util.losses import (add_drc_loss, add_proj_depth_loss, add_proj_rgb_loss,  # noqa: F401
                           resize_images_bilinear_tf1)
 from .util.point_cloud import pc_point_dropout, pointcloud_project, pointcloud_project_fast
-from .util.quaternion import quaternion_conjugate as q_conj
-from .util.quaternion import quaternion_multiply as q_mul
-from .util.quaternion import quaternion_normalise as q_norm
 from .util.quaternion import quaternion_rotate as q_rotate
 
 
@@ -236,23 +233,23 @@ class ModelPointCloud(object):
 
     def add_student_loss(self, inputs, outputs, min_loss, add_summary=False):    # model_pc.py:338-381
         """Distil the winning pose candidate (teacher, no gradient) into the student
-        quaternion: sum(1 - cos^2 of half the relative angle) / num_samples * weight."""
+        quaternion: sum(1 - cos^2 of half the relative angle) / num_samples * weight.
+        The default branch is one HIP kernel (ops.StudentLoss: loss and d loss / d student together); the
+        align-loss variant stays on the quaternion helpers."""
         cfg = self.cfg()
         C = cfg.pose_predict_num_candidates
         student = outputs["pose_student"]
-        teachers = outputs["poses"].reshape(-1, C, 4)
-        teachers = teachers[torch.arange(teachers.shape[0], device=teachers.device), min_loss].detach()
-        weights = inputs["valid_samples"] if cfg.variable_num_views else 1.0
         if getattr(cfg, "pose_student_align_loss", False):                    # model_pc.py:362-368
+            teachers = outputs["poses"].reshape(-1, C, 4)
+            teachers = teachers[torch.arange(teachers.shape[0], device=teachers.device), min_loss].detach()
             ref_pc = self._pc_for_alignloss
             ref_all = ref_pc.unsqueeze(0).expand(teachers.shape[0], -1, -1)
             diff = q_rotate(ref_all, teachers) - q_rotate(ref_all, student)
             student_loss = (diff * diff).sum() / 2 / float(ref_pc.shape[0]) / float(min_loss.shape[0])
-        else:
-            q_diff = q_norm(q_mul(teachers, q_conj(student)))
-            angle_diff = q_diff[:, 0]
-            student_loss = ((1.0 - angle_diff ** 2) * weights).sum() / float(min_loss.shape[0])
-        return student_loss * cfg.pose_predictor_student_loss_weight
+            return student_loss * cfg.pose_predictor_student_loss_weight
+        weights = inputs["valid_samples"] if cfg.variable_num_views else None
+        return ops.StudentLoss.apply(student, outputs["poses"].detach(), min_loss, weights, C,
+                                     float(cfg.pose_predictor_student_loss_weight))
 
     def add_proj_loss(self, inputs, outputs, weight_scale, add_summary=False):   # model_pc.py:383-423
         cfg = self.cfg()

@@ -510,6 +510,42 @@ class SilhouetteLoss(torch.autograd.Function):
         return dproj, None, None, None
 
 
+class StudentLoss(torch.autograd.Function):
+    """add_student_loss, default branch (dpc/models/model_pc.py:338-381): poses [n*C,4] (teachers, no gradient),
+    winners [n] int64, student [n,4], weights [n] | None -> scalar loss; one kernel computes the loss and
+    d loss / d student."""
+
+    @staticmethod
+    def forward(ctx, student, poses, winners, weights, num_candidates, scale):
+        C = int(num_candidates)
+        if student.dim() != 2 or student.shape[1] != 4:
+            raise ValueError("student must be [n,4] quaternions, got %s" % (tuple(student.shape),))
+        n = student.shape[0]
+        if poses.numel() != n * C * 4:
+            raise ValueError("poses must hold %d x %d candidate quaternions, got %s" % (n, C, tuple(poses.shape)))
+        if winners.numel() != n or winners.dtype != torch.int64:
+            raise ValueError("winners must be %d int64 candidate indices" % n)
+        if weights is not None:
+            if weights.numel() != n:
+                raise ValueError("weights must have %d elements, got %d" % (n, weights.numel()))
+            weights = _c(weights.to(device=student.device, dtype=torch.float32).reshape(-1))
+        lib = _lib_for(student, poses, weights)
+        _lib_for(winners, dtypes=(torch.int64,))
+        student, poses, winners = _c(student), _c(poses), _c(winners)
+        loss = torch.empty((), dtype=torch.float32, device=student.device)
+        dstudent = torch.empty_like(student)
+        rc = lib.dpc_student_loss(_stream(lib, student), n, C, _p(poses), _p(winners), _p(student), _p(weights),
+                                  float(scale), _p(loss), _p(dstudent))
+        lib.check(rc, "dpc_student_loss")
+        ctx.save_for_backward(dstudent)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dstudent,) = ctx.saved_tensors
+        return dstudent * dloss, None, None, None, None, None
+
+
 class NNDistance(torch.autograd.Function):
     """point_cloud_distance (dpc/util/point_cloud_distance.py:26-39): Vs [Ns,3], Vt [Nt,3]
     (float32 or float64) -> (proj [Ns,3] = Vt[idx], minDist [Ns], idx [Ns] int32)."""

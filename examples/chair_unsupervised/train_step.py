@@ -94,7 +94,8 @@ def main():
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[device.index], bucket_cap_mb=64,
                                                           gradient_as_bucket_view=True)
     projector = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device=device)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=args.graph)
+    torch.backends.cudnn.benchmark = True          # MIOpen find mode for the stock convolutions
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=args.graph, fused=True)
     inputs = synthetic_batch(cfg, device, args.image_size, seed=rank)
     run = lambda: train_step(model, projector, inputs, opt, world)
     if args.graph:

@@ -230,6 +230,16 @@ int dpc_silhouette_loss_fwd(dpc_stream_t stream, int B, int C, int D, int S, con
 int dpc_silhouette_loss_bwd(dpc_stream_t stream, int B, int C, int D, int S, const float* proj,
                             const float* gt, const float* weight, const float* dloss, float* dproj);
 
+/* Student pose loss: replaces the default branch of add_student_loss (dpc/models/model_pc.py:338-381;
+ * quaternion_multiply / quaternion_conjugate / quaternion_normalise of dpc/util/quaternion.py:32-117 composed
+ * there).  poses [n*C,4] candidate quaternions (w,x,y,z), sample-major; winners [n] int64 = the arg-min candidate
+ * of every sample (dpc_silhouette_loss_fwd's output, widened); student [n,4]; weights [n] or NULL
+ * (inputs["valid_samples"]).  With p = teacher (x) conj(student), a = p_w / |p|:
+ * loss [1] = scale / n * sum_i w_i (1 - a_i^2), dstudent [n,4] = d loss / d student (the teacher carries no
+ * gradient: tf.stop_gradient).  scale = cfg.pose_predictor_student_loss_weight. */
+int dpc_student_loss(dpc_stream_t stream, int n, int C, const float* poses, const int64_t* winners,
+                     const float* student, const float* weights, float scale, float* loss, float* dstudent);
+
 /* Nearest-neighbour distance: replaces point_cloud_distance
  * (dpc/util/point_cloud_distance.py:26-39), the kernel of the Chamfer evaluation
  * (dpc/run/eval_chamfer.py:18-34, fp64 there).  vs [ns,3], vt [nt,3] in the

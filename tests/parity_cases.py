@@ -477,6 +477,30 @@ def fused_l2_epilogue_equals_the_autograd_loss(dev, B=3, N=300, D=32, K=5):
         dpc_amd.pointcloud_project_fast(cfg_max, pc, pose, None, None, kern, scaling_factor=scale, l2_target=(gt, w))
 
 
+def student_loss_equals_the_quaternion_composite(dev, n=37, C=4, seed=5):
+    """ops.StudentLoss (one kernel) == the reference's composite of quaternion_multiply / conjugate / normalise
+    (model_pc.py:338-381), value and gradient, with and without valid_samples weights; unnormalised inputs."""
+    from dpc_amd.util import quaternion as Q
+    rng = np.random.default_rng(seed)
+    poses = torch.tensor(rng.standard_normal((n * C, 4)).astype(np.float32), device=dev)
+    winners = torch.tensor(rng.integers(0, C, n), device=dev, dtype=torch.int64)
+    for weights in (None, torch.tensor(rng.uniform(0, 1, n).astype(np.float32), device=dev)):
+        s1 = torch.tensor(rng.standard_normal((n, 4)).astype(np.float32), device=dev, requires_grad=True)
+        s2 = s1.detach().clone().requires_grad_(True)
+        loss = dpc_amd.ops.StudentLoss.apply(s1, poses, winners, weights, C, 20.0)
+        (loss * 0.7).backward()
+        teachers = poses.reshape(n, C, 4)[torch.arange(n, device=dev), winners]
+        a = Q.quaternion_normalise(Q.quaternion_multiply(teachers, Q.quaternion_conjugate(s2)))[:, 0]
+        ref = ((1.0 - a ** 2) * (1.0 if weights is None else weights)).sum() / float(n) * 20.0
+        (ref * 0.7).backward()
+        assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+        assert relerr(s1.grad.cpu().numpy(), s2.grad.cpu().numpy()) < 2e-6
+    with pytest.raises(ValueError):
+        dpc_amd.ops.StudentLoss.apply(s1, poses[:-4], winners, None, C, 1.0)
+    with pytest.raises(ValueError):
+        dpc_amd.ops.StudentLoss.apply(s1, poses, winners.to(torch.int32), None, C, 1.0)
+
+
 def knife_edge_inputs_match_reference_conventions(dev, D, Dz):
     """NO nudging: points that sit EXACTLY on lattice nodes / cell faces / the faces of the unit cube, a node
     that receives exactly 1.0 (clip_by_value(G0,0,1) must still pass its gradient: closed interval), a node

@@ -293,6 +293,12 @@ def test_asymmetric_filters(D, K):
     parity_cases.asymmetric_filters_against_cpu_oracle("cuda", D, K)
 
 
+def test_student_loss():
+    parity_cases.student_loss_equals_the_quaternion_composite("cuda")
+    parity_cases.student_loss_equals_the_quaternion_composite("cuda", n=80, C=4, seed=1)
+    parity_cases.student_loss_equals_the_quaternion_composite("cuda", n=300, C=2, seed=9)
+
+
 def test_fused_l2_epilogue():
     parity_cases.fused_l2_epilogue_equals_the_autograd_loss("cuda")
     parity_cases.fused_l2_epilogue_equals_the_autograd_loss("cuda", B=32, N=8000, D=128, K=11)    # cfg2 (what bench.py times)

@@ -16,6 +16,11 @@ def test_emu_asymmetric_filters(emu, D, K):
     parity_cases.asymmetric_filters_against_cpu_oracle("cpu", D, K)
 
 
+def test_emu_student_loss(emu):
+    parity_cases.student_loss_equals_the_quaternion_composite("cpu")
+    parity_cases.student_loss_equals_the_quaternion_composite("cpu", n=300, C=2, seed=9)      # more samples than threads
+
+
 def test_emu_fused_l2_epilogue(emu):
     parity_cases.fused_l2_epilogue_equals_the_autograd_loss("cpu")
     parity_cases.fused_l2_epilogue_equals_the_autograd_loss("cpu", B=2, N=100, D=16, K=5)      # generic path: same kernel tail
