@@ -23,7 +23,9 @@ class ImgEncoder(nn.Module):
         for _ in range(num_blocks):
             layers += [nn.Conv2d(c, 2 * c, 3, stride=2, padding=1), act, nn.Conv2d(2 * c, 2 * c, 3, padding=1), act]
             c *= 2
-        self.conv = nn.Sequential(*layers)
+        # the images arrive NHWC (forward permutes a view): keep the filters in the matching layout, otherwise every
+        # convolution converts its weights on every call
+        self.conv = nn.Sequential(*layers).to(memory_format=torch.channels_last)
         self.fc1 = nn.Linear(c * 4 * 4, fc_dim)
         self.fc2 = nn.Linear(fc_dim, fc_dim)
         self.fc3 = nn.Linear(fc_dim, z_dim)
