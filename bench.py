@@ -222,7 +222,10 @@ def main():
     ap.add_argument("--projector-only", action="store_true", help="config 3: time the projector alone at the training shape")
     ap.add_argument("--keep-prob", type=float, default=1.0, help="config 3: point dropout keep probability (N = 8000 * keep)")
     ap.add_argument("--graph", action="store_true",
-                    help="capture one fwd+bwd step in a HIP graph and replay it (launch-bound small configs)")
+                    help="record one step into a HIP graph and replay it: the default for the projector workloads (the "
+                         "library only enqueues on the stream it is handed; a 7-launch step is otherwise at the mercy "
+                         "of the host's enqueue rate), opt-in for the training step (--config 3, single GPU)")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly from Python")
     ap.add_argument("--repeats", type=int, default=None,
                     help="extra HIP-event-timed blocks of --steps steps for median/p10/p90 (default: >= 10, >= 1 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -251,6 +254,10 @@ def main():
 
     lib = dpc_amd.get_library()
     train = args.config == 3 and not args.projector_only
+    if args.graph and args.no_graph:
+        raise SystemExit("--graph and --no-graph exclude each other")
+    if not train and not args.no_graph and not DRY_RUN:
+        args.graph = True
     if os.environ.get("DPC_CUDNN_BENCHMARK"):     # dev switch: MIOpen find mode for the stock PyTorch layers
         torch.backends.cudnn.benchmark = os.environ["DPC_CUDNN_BENCHMARK"] == "1"
     if train:

@@ -19,12 +19,18 @@ fi
 echo "== bench lines"
 timeout 600 python bench.py --gpus 1 --steps 50 --warmup 10 > "$OUT/03_bench_cfg2.json" 2> "$OUT/03_bench_cfg2.err"; echo "cfg2 rc=$?"
 timeout 300 python bench.py --gpus 1 --steps 30 --warmup 5 --config 5 --no-cpu-baseline > "$OUT/04_bench_cfg5.json" 2> "$OUT/04_bench_cfg5.err"
+timeout 300 python bench.py --gpus 1 --steps 50 --warmup 10 --no-graph --no-cpu-baseline > "$OUT/04_bench_cfg2_eager.json" 2> "$OUT/04_bench_cfg2_eager.err"
+timeout 300 python bench.py --gpus 1 --steps 50 --warmup 10 --config 1 --no-graph --no-cpu-baseline > "$OUT/04_bench_cfg1_eager.json" 2> "$OUT/04_bench_cfg1_eager.err"
 timeout 300 python bench.py --gpus 1 --steps 50 --warmup 10 --config 1 --no-cpu-baseline > "$OUT/04_bench_cfg1.json" 2> "$OUT/04_bench_cfg1.err"
-timeout 300 python bench.py --gpus 1 --steps 50 --warmup 10 --config 1 --graph --no-cpu-baseline > "$OUT/04_bench_cfg1_graph.json" 2> "$OUT/04_bench_cfg1_graph.err"
 timeout 300 python bench.py --gpus 1 --steps 30 --warmup 5 --points ball --no-cpu-baseline > "$OUT/04_bench_cfg2_ball.json" 2> "$OUT/04_bench_cfg2_ball.err"
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --config 3 --cpu-seconds 8 > "$OUT/05_bench_cfg3_train.json" 2> "$OUT/05_bench_cfg3_train.err"
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --config 3 --keep-prob 0.07 --no-cpu-baseline > "$OUT/05_bench_cfg3_train_keep007.json" 2> "$OUT/05_bench_cfg3_train_keep007.err"
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --config 3 --keep-prob 0.5 --no-cpu-baseline > "$OUT/05_bench_cfg3_train_keep05.json" 2> "$OUT/05_bench_cfg3_train_keep05.err"
+for KP in 1.0 0.5 0.07; do
+  timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --config 3 --graph --keep-prob $KP --no-cpu-baseline > "$OUT/05_bench_cfg3_train_graph_keep$KP.json" 2> "$OUT/05_bench_cfg3_train_graph_keep$KP.err"
+done
+timeout 300 python examples/chair_unsupervised/train_step.py --steps 40 --warmup 5 --keep-prob 0.07 --scheduled --max-steps 45 --graph > "$OUT/09_train_step_example_graph.json" 2> "$OUT/09_train_step_example_graph.err"
+timeout 300 python examples/chair_unsupervised/train_step.py --steps 40 --warmup 5 --keep-prob 0.07 --scheduled --max-steps 45 > "$OUT/09_train_step_example_eager.json" 2> "$OUT/09_train_step_example_eager.err"
 timeout 300 python bench.py --gpus 1 --steps 30 --warmup 5 --config 3 --projector-only --no-cpu-baseline > "$OUT/05_bench_cfg3_proj.json" 2> "$OUT/05_bench_cfg3_proj.err"
 timeout 300 python bench.py --gpus 1 --steps 30 --warmup 5 --config 3 --projector-only --num-points 560 --no-cpu-baseline > "$OUT/05_bench_cfg3_proj_n560.json" 2> "$OUT/05_bench_cfg3_proj_n560.err"
 python - "$OUT" <<'PY'
@@ -43,12 +49,12 @@ cd /tmp
 prof() {  # name, bench args
   NAME=$1; shift
   timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_stats_$NAME" -o $NAME --output-format csv -- \
-      python "$REPO/bench.py" --gpus 1 --steps 20 --warmup 5 --repeats 0 --no-cpu-baseline "$@" > "$OUT/06_rocprof_stats_$NAME.log" 2>&1
+      python "$REPO/bench.py" --gpus 1 --steps 20 --warmup 5 --repeats 0 --no-graph --no-cpu-baseline "$@" > "$OUT/06_rocprof_stats_$NAME.log" 2>&1
   echo "rocprof stats $NAME exit $?"
   if [ -z "$SKIP_PMC" ]; then
     for CTR in FETCH_SIZE WRITE_SIZE; do
       timeout 600 rocprofv3 --pmc $CTR --kernel-trace -d "$OUT/prof_pmc_${CTR}_$NAME" -o $NAME --output-format csv -- \
-          python "$REPO/bench.py" --gpus 1 --steps 5 --warmup 2 --repeats 0 --no-cpu-baseline "$@" > "$OUT/07_rocprof_pmc_${CTR}_$NAME.log" 2>&1
+          python "$REPO/bench.py" --gpus 1 --steps 5 --warmup 2 --repeats 0 --no-graph --no-cpu-baseline "$@" > "$OUT/07_rocprof_pmc_${CTR}_$NAME.log" 2>&1
       echo "pmc $CTR $NAME exit $?"
     done
   fi

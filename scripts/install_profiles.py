@@ -20,6 +20,8 @@ for a, b in names.items():
     shutil.copy(os.path.join(src, a), os.path.join(dst, "%s_%s" % (pre, b)))
 for f in glob.glob(os.path.join(src, "0[345]_bench_*.json")):
     shutil.copy(f, os.path.join(dst, "%s_%s" % (pre, os.path.basename(f)[3:])))
+for f in glob.glob(os.path.join(src, "09_train_step_example_*.json")):
+    shutil.copy(f, os.path.join(dst, "%s_%s" % (pre, os.path.basename(f)[3:])))
 for cfg in ("cfg2", "cfg3p", "cfg5"):
     shutil.copy(os.path.join(src, "prof_stats_%s" % cfg, "%s_kernel_stats.csv" % cfg),
                 os.path.join(dst, "%s_%s_kernel_stats.csv" % (pre, cfg)))
