@@ -256,6 +256,7 @@ def main():
     train = args.config == 3 and not args.projector_only
     if args.graph and args.no_graph:
         raise SystemExit("--graph and --no-graph exclude each other")
+    explicit_graph = bool(args.graph)
     if not train and not args.no_graph and not DRY_RUN:
         args.graph = True
     if os.environ.get("DPC_CUDNN_BENCHMARK"):     # dev switch: MIOpen find mode for the stock PyTorch layers
@@ -282,19 +283,31 @@ def main():
         with torch.cuda.graph(graph):
             case["graph_loss"] = case["run"]()
         run = graph.replay
+    graph_note = None
     if args.graph and not train:
-        # the library only enqueues on the stream it is handed, so a whole step (forward, loss
-        # gradient, backward) records into one hipGraph; replay costs one launch on the host
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                step(case)
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            case["graph_grads"] = step(case)
-        run = graph.replay
+        # the library only enqueues on the stream it is handed, so a whole step (forward with the loss
+        # gradient, backward) records into one hipGraph; replay costs one launch on the host.  Capture is
+        # per rank and thread-local (an RCCL watchdog thread may touch the runtime meanwhile); if it fails on
+        # some runtime the run goes on eagerly and says so in the line.
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step(case)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                case["graph_grads"] = step(case)
+            run = graph.replay
+        except Exception as e:                       # noqa: BLE001 -- report, do not lose the measurement
+            if explicit_graph:
+                raise
+            torch.cuda.synchronize()
+            args.graph, graph_note = False, "HIP graph capture failed (%s: %s); eager launches" % (type(e).__name__, e)
+            sys.stderr.write("[rank %d] %s\n" % (rank, graph_note))
+            run = lambda: step(case)
     for _ in range(args.warmup):
         run()
     dd.barrier(device)                      # barrier + torch.cuda.synchronize() on both sides
@@ -386,7 +399,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not DRY_RUN else "dry run on the CPU emulation library: NOT a measurement",
             "config": {"workload": workload, "global_batch": world * case["B"], "K": case["K"],
-                       "hip_graph": bool(args.graph), "training_step": bool(train),
+                       "hip_graph": bool(args.graph), **({"hip_graph_note": graph_note} if graph_note else {}),
+                       "training_step": bool(train),
                        "parallelism": ("models sharded x%d (DDP), gradient all-reduce over RCCL" % world) if train else
                                       ("views sharded x%d, no data-path collective" % world)},
             "timing": None if not blocks else {
