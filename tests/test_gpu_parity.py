@@ -491,3 +491,36 @@ def test_graph_replay_follows_the_dropout_and_sigma_schedules():
         assert err == 0.0 if keep < 4096 else err < 2e-6, (step, keep, err)
     assert len(set(seeds)) == len(seeds)                                  # a fresh draw per replay
     assert all(np.isfinite(losses))
+
+
+def test_bench_line_contract_on_the_gpu():
+    """`python bench.py` as the driver runs it (here at a toy step count): one JSON line with the contract's keys,
+    the roofline and timing objects, the step replayed as a HIP graph; `--no-graph` gives the eager figure, and the
+    gradients a replay leaves equal the eager ones (the recorded step is the measured step)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("DPC_POISON_BUFFERS", "DPC_TEST_HOOKS", "DPC_BENCH_DRY_RUN", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    lines = {}
+    for extra in ([], ["--no-graph"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--repeats", "2",
+                            "--no-cpu-baseline"] + extra, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(out) == 1, r.stdout
+        lines[bool(extra)] = json.loads(out[0])
+    j = lines[False]
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "timing"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 5 and j["warmup"] == 2 and j["unit"] == "views/s" and j["dtype"] == "f32"
+    assert j["config"]["hip_graph"] is True and lines[True]["config"]["hip_graph"] is False
+    assert abs(j["value"] * j["ms_per_step"] / 1e3 - 32.0) < 1e-6 * 32         # value = views / time
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1.2 and r["traffic"]
+    assert 0.5 < lines[True]["value"] / j["value"] < 2.0
