@@ -250,7 +250,14 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a ROCm GPU (the projector has no CPU fallback)")
-        rank, world, device = dd.init("nccl")
+        if os.environ.get("DPC_BENCH_SHARE_GPU") == "1":
+            # dev hook: every rank on cuda:0 with gloo as the rendezvous -- exercises the launcher, the per-rank graph
+            # capture, the barriers and the reporting on a ONE-GPU box (RCCL refuses two ranks on one device).
+            # The number it prints is NOT a measurement (the ranks share the GPU).
+            torch.cuda.set_device(0)
+            rank, world, device = dd.init("gloo", device=torch.device("cuda", 0))
+        else:
+            rank, world, device = dd.init("nccl")
 
     lib = dpc_amd.get_library()
     train = args.config == 3 and not args.projector_only
@@ -397,7 +404,9 @@ def main():
             "value": views / elapsed, "unit": "views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic" if not DRY_RUN else "dry run on the CPU emulation library: NOT a measurement",
+            "data": ("dry run on the CPU emulation library: NOT a measurement" if DRY_RUN else
+                     "ranks share one GPU (DPC_BENCH_SHARE_GPU): NOT a measurement"
+                     if os.environ.get("DPC_BENCH_SHARE_GPU") == "1" else "synthetic"),
             "config": {"workload": workload, "global_batch": world * case["B"], "K": case["K"],
                        "hip_graph": bool(args.graph), **({"hip_graph_note": graph_note} if graph_note else {}),
                        "training_step": bool(train),
