@@ -28,6 +28,9 @@ def test_emu_fused_l2_epilogue(emu):
 
 def test_emu_fused_dropout(emu):
     parity_cases.fused_dropout_equals_explicit_subset("cpu")
+    # the device permutation against the oracle's at awkward sizes (2^k +- 1, tiny)
+    for N, keep in ((65, 7), (129, 128), (33, 1), (5, 2)):
+        parity_cases.fused_dropout_equals_explicit_subset("cpu", B=2, N=N, D=32, K=5, keep=keep, seed=1234 + N)
 
 
 @pytest.mark.parametrize("D,Dz", [(32, 33), (33, 33)])      # fused path / generic path (D-1 = 32: exact interior faces)
@@ -61,6 +64,24 @@ def test_dropout_reference_permutation_properties():
     assert (m.sum(1) == 560).all()
     # marginal keep rate per point over instances ~ 560/8000 (binomial, 16 draws): nothing systematically kept
     assert m.mean(0).max() <= 7 / 16
+
+
+def test_dropout_permutation_is_a_bijection_for_any_size_and_key():
+    """Property (hypothesis): the keyed unbalanced-Feistel permutation with cycle walking is a bijection of [0, N)
+    for every N (powers of two, their neighbours, primes, 1), seed and instance; different instances of one seed
+    get different permutations."""
+    from hypothesis import given, settings, strategies as st
+    from oracle import dropout_ref
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.one_of(st.integers(1, 70), st.sampled_from([127, 128, 129, 1023, 1024, 1025, 4093, 8000, 8191, 8192, 8193, 16000])),
+           st.integers(0, 2 ** 32 - 1), st.integers(0, 4095))
+    def check(N, seed, b):
+        r = dropout_ref.dropout_rank(N, seed, b)
+        assert r.shape == (N,) and np.array_equal(np.sort(r), np.arange(N, dtype=r.dtype))
+        if N >= 64:
+            assert not np.array_equal(r, dropout_ref.dropout_rank(N, seed, b + 1))
+    check()
 
 
 def test_matrix_pose_focal_has_no_gradient(emu):
