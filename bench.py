@@ -275,7 +275,7 @@ def main():
         case = build_case(args.config, args.batch, device, seed_offset=1000 * rank, kind=args.points, N=args.num_points)
         run = lambda: step(case)
     if args.graph and train:
-        # The training step is ~420 launches (stock PyTorch layers, optimiser, the projector's 10 kernels): eager,
+        # The training step is ~280 launches (stock PyTorch layers, fused optimiser, the library's 10 kernels): eager,
         # the host sets the pace.  The whole step -- nets, projector, loss epilogue, backward, Adam -- is recorded
         # into ONE hipGraph (the library only enqueues on the stream it is handed) and replayed.
         if world > 1:
