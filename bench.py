@@ -25,8 +25,12 @@ Rank 0 prints ONE JSON line.  `value` comes from EXACTLY --steps steps after --w
 by barrier + torch.cuda.synchronize() on both sides, max over ranks.  Besides the contract keys:
   timing       --repeats further blocks of --steps steps, each timed with HIP events: median / p10 / p90
   roofline     dominant projector kernel: algorithmic bytes per launch / its mean launch duration (HIP events
-               on the launch stream, dpc_profile_*), against the 8 TB/s HBM3E peak; step_* = the projector's
-               whole fwd+bwd against SURVEY.md 8(d)'s 8 V + P bytes per view
+               on the launch stream, dpc_profile_*), against the 8 TB/s HBM3E peak AND against a float4 copy
+               measured in this run (copy_ceiling, frac_of_ceiling); traffic = PMC-measured HBM bytes of that
+               launch (profiles/traffic.json), measured_achieved = traffic / duration.  step_* = the projector's
+               whole fwd+bwd: step_alg_bytes is SURVEY.md 8(d)'s stage MODEL (8 V + P per view: an unfused
+               pipeline's compulsory traffic), step_alg_bytes_impl what THIS implementation has to move (5 V + P
+               when the xy-blurred grid is what is saved, 6 V + P otherwise), step_measured_bytes the PMC sum
   cpu_baseline oracle/reference_cpu.py (op-for-op torch-CPU restatement of the reference graph, kind "port")
                on a bounded sample on this host's cores (rank 0, N = 1 only)
 """
@@ -88,8 +92,12 @@ def build_train_case(args, device, rank, world):
     cfg = ts.make_cfg(batch_size=models, pc_point_dropout=args.keep_prob, pc_point_dropout_scheduled=False, **toy)
     torch.manual_seed(0)
     net = Im2PointCloud(cfg, image, **net_kw).to(device)
-    model = net
-    if world > 1:
+    model, buckets = net, None
+    if world > 1 and args.graph:
+        # a recorded step cannot hold DDP's reducer (host-side bucket bookkeeping between steps): the same bucketed,
+        # backward-overlapped all-reduce is issued by gradient hooks instead (dpc_amd.distributed.GradBuckets)
+        buckets = dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=64)
+    elif world > 1:
         ddp_kw = dict(device_ids=[device.index]) if device.type == "cuda" else {}
         model = torch.nn.parallel.DistributedDataParallel(net, bucket_cap_mb=64, gradient_as_bucket_view=True, **ddp_kw)
     projector = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device=device)
@@ -98,15 +106,16 @@ def build_train_case(args, device, rank, world):
     fused = device.type == "cuda" and os.environ.get("DPC_ADAM_FUSED", "1") == "1"
     if device.type == "cuda" and "DPC_CUDNN_BENCHMARK" not in os.environ:
         torch.backends.cudnn.benchmark = True
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=bool(args.graph), **({"fused": True} if fused else {}))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=bool(args.graph) and not DRY_RUN, **({"fused": True} if fused else {}))
     inputs = ts.synthetic_batch(cfg, device, image, seed=rank)
     views = cfg.batch_size * cfg.step_size * cfg.pose_predict_num_candidates
-    if args.graph:
+    if args.graph and not DRY_RUN:
         projector.enable_graph_replay()        # blur taps and the dropout's {keep, seed} at fixed device addresses
     case = dict(B=views, N=int(cfg.pc_num_points * args.keep_prob), D=cfg.vox_size, K=cfg.pc_gauss_kernel_size,
                 sigma=cfg.pc_relative_sigma, models=models, params=sum(p.numel() for p in net.parameters()),
                 views_per_model=cfg.step_size, candidates=cfg.pose_predict_num_candidates,
-                run=lambda: ts.train_step(model, projector, inputs, opt, world))
+                reducer="GradBuckets" if buckets is not None else ("DDP" if world > 1 else None),
+                run=lambda: ts.train_step(model, projector, inputs, opt, world, buckets=buckets))
     return case
 
 
@@ -192,6 +201,30 @@ def cpu_baseline(cfg_id, seconds_budget=20.0):
             "host_cpus": ncpu, "cpu_model": _cpu_model()}
 
 
+def copy_ceiling(lib, device, mbytes=512, reps=20):
+    """On-box HBM ceiling: the library's float4 streaming copy (k_copy<4>, 16 B per lane) over a
+    buffer far larger than the 256 MiB Infinity Cache, timed with HIP events on the launch stream."""
+    import ctypes
+    n = mbytes * (1 << 20) // 4
+    src = torch.empty(n, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    call = lambda: lib.check(lib.dpc_debug_copy(st, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), n, 4),
+                             "dpc_debug_copy")
+    for _ in range(3):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return {"GB/s": 2.0 * n * 4 / (ms * 1e-3) / 1e9, "bytes_moved": 2 * n * 4, "ms": ms,
+            "method": "dpc_debug_copy (k_copy<4>: 16 B per lane, read + write), %d MiB -> %d MiB, mean of %d launches, "
+                      "HIP events" % (mbytes, mbytes, reps)}
+
+
 def self_launch(ngpus, argv):
     """`python bench.py --gpus N` outside a launcher: start N ranks through torch.distributed.run."""
     with socket.socket() as s:
@@ -228,6 +261,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly from Python")
     ap.add_argument("--repeats", type=int, default=None,
                     help="extra HIP-event-timed blocks of --steps steps for median/p10/p90 (default: >= 10, >= 1 s)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): the config's batch PER GPU; strong: the config's batch split over the GPUs "
+                         "(SURVEY.md 8(e): secondary, latency-bound at 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -269,28 +305,52 @@ def main():
     if os.environ.get("DPC_CUDNN_BENCHMARK"):     # dev switch: MIOpen find mode for the stock PyTorch layers
         torch.backends.cudnn.benchmark = os.environ["DPC_CUDNN_BENCHMARK"] == "1"
     if train:
+        if args.scaling == "strong" and world > 1:
+            total = args.batch or 16
+            lo, hi = dd.shard_range(total, rank, world)
+            if (hi - lo) * world != total:
+                raise SystemExit("--scaling strong: %d models do not split evenly over %d ranks" % (total, world))
+            args.batch = hi - lo
         case = build_train_case(args, device, rank, world)
         run = case["run"]
     else:
-        case = build_case(args.config, args.batch, device, seed_offset=1000 * rank, kind=args.points, N=args.num_points)
+        batch = args.batch
+        if args.scaling == "strong" and world > 1:
+            total = batch or dpc_amd.synthetic.CONFIGS[args.config]["B"]
+            lo, hi = dd.shard_range(total, rank, world)          # this rank's contiguous slice of the global batch
+            if hi - lo == 0:
+                raise SystemExit("--scaling strong: %d views do not split over %d ranks" % (total, world))
+            batch = hi - lo
+        case = build_case(args.config, batch, device, seed_offset=1000 * rank, kind=args.points, N=args.num_points)
         run = lambda: step(case)
+    graph_note = None
+    if args.graph and train and DRY_RUN:
+        args.graph, graph_note = False, "dry run: the recordable reducer (GradBuckets) runs eagerly under gloo"
     if args.graph and train:
         # The training step is ~280 launches (stock PyTorch layers, fused optimiser, the library's 10 kernels): eager,
-        # the host sets the pace.  The whole step -- nets, projector, loss epilogue, backward, Adam -- is recorded
-        # into ONE hipGraph (the library only enqueues on the stream it is handed) and replayed.
-        if world > 1:
-            raise SystemExit("--graph with --config 3 is single-GPU (DDP's bucketed all-reduce is not captured here)")
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):                     # allocator, MIOpen solver search, Adam state
-                case["run"]()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            case["graph_loss"] = case["run"]()
-        run = graph.replay
-    graph_note = None
+        # the host sets the pace.  The whole step -- nets, projector, loss epilogue, backward, (N > 1: the bucketed RCCL
+        # all-reduce of the gradients, issued from gradient hooks and overlapped with the backward pass,) Adam -- is
+        # recorded into ONE hipGraph per rank (the library only enqueues on the stream it is handed) and replayed.
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3 if world == 1 else 11):   # allocator, MIOpen solver search, Adam state, RCCL channels
+                    case["run"]()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            dd.barrier(device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                case["graph_loss"] = case["run"]()
+            run = graph.replay
+        except Exception as e:                       # noqa: BLE001 -- report, do not lose the measurement
+            if world == 1:
+                raise
+            torch.cuda.synchronize()
+            args.graph, graph_note = False, "HIP graph capture failed (%s: %s); eager launches" % (type(e).__name__, e)
+            sys.stderr.write("[rank %d] %s\n" % (rank, graph_note))
+            run = case["run"]
     if args.graph and not train:
         # the library only enqueues on the stream it is handed, so a whole step (forward with the loss
         # gradient, backward) records into one hipGraph; replay costs one launch on the host.  Capture is
@@ -363,7 +423,7 @@ def main():
         dom_ms = agg[dom][1] / agg[dom][0]
         save_xy = lib.saves_xy(case["B"], case["N"], case["D"], case["K"])
         alg = kernel_algorithmic_bytes(dom, case, save_xy)
-        traffic, tsrc = None, None
+        traffic, tsrc, ent = None, None, {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
@@ -373,16 +433,35 @@ def main():
             except (ValueError, OSError):
                 pass
         step_bytes = dpc_amd.synthetic.algorithmic_bytes_per_view(case["N"], case["D"], case["D"]) * case["B"]
+        # what THIS implementation has to move per view: splat 1 V (write), collapse 1 V (read; + 1 V when it also
+        # stores G2), collapse VJP 2 V, gather 1 V -- the raw grid and the y/x-blurred gradient grid never exist
+        V = 4 * case["D"] ** 3
+        impl_bytes = step_bytes - (3 if save_xy else 2) * V * case["B"]
+        step_traffic = None
+        if tsrc is not None:
+            step_traffic = ent.get("_step_total")
         proj_ms = sum(per_step.values()) if train else ms_step     # config 3: the projector's share of the step
-        roof = {"bound": "hbm", "kernel": dom, "achieved": alg / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": alg / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+        ceiling = copy_ceiling(lib, device)
+        ach = alg / (dom_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": tsrc, "kernel_ms": dom_ms, "kernel_alg_bytes": alg,
+                "measured_achieved": None if traffic is None else traffic / (dom_ms * 1e-3) / 1e9,
+                "copy_ceiling": ceiling, "frac_of_ceiling": ach / ceiling["GB/s"],
                 "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items())},
-                "step_alg_bytes": step_bytes, "step_ms": proj_ms,
+                "step_alg_bytes": step_bytes, "step_alg_bytes_impl": impl_bytes, "step_measured_bytes": step_traffic,
+                "step_ms": proj_ms,
                 "step_scope": ("library kernels only (sum of their HIP-event durations inside the training step)"
                                if train else "whole timed step"),
                 "step_achieved": step_bytes / (proj_ms * 1e-3) / 1e9,
-                "step_frac": step_bytes / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                "step_frac": step_bytes / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "step_impl_achieved": impl_bytes / (proj_ms * 1e-3) / 1e9,
+                "step_impl_frac": impl_bytes / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "step_impl_frac_of_ceiling": impl_bytes / (proj_ms * 1e-3) / 1e9 / ceiling["GB/s"],
+                "step_measured_achieved": None if step_traffic is None else step_traffic / (proj_ms * 1e-3) / 1e9,
+                "which_is_which": "frac/step_frac: SURVEY 8(d) byte MODEL over the 8 TB/s spec peak; *_impl: the bytes this "
+                                  "implementation must move; measured_*: PMC bytes (rocprofv3, profiles/traffic.json); "
+                                  "*_of_ceiling: over the float4 copy measured in this run"}
 
     if rank == 0:
         views = world * case["B"] * args.steps
@@ -403,14 +482,14 @@ def main():
                       % (case["N"], case["D"], case["D"], case["B"]),
             "value": views / elapsed, "unit": "views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "data": ("dry run on the CPU emulation library: NOT a measurement" if DRY_RUN else
                      "ranks share one GPU (DPC_BENCH_SHARE_GPU): NOT a measurement"
                      if os.environ.get("DPC_BENCH_SHARE_GPU") == "1" else "synthetic"),
             "config": {"workload": workload, "global_batch": world * case["B"], "K": case["K"],
                        "hip_graph": bool(args.graph), **({"hip_graph_note": graph_note} if graph_note else {}),
                        "training_step": bool(train),
-                       "parallelism": ("models sharded x%d (DDP), gradient all-reduce over RCCL" % world) if train else
+                       "parallelism": ("models sharded x%d (%s), gradient all-reduce over RCCL" % (world, case.get("reducer") or "DDP")) if train else
                                       ("views sharded x%d, no data-path collective" % world)},
             "timing": None if not blocks else {
                 "repeats": len(blocks), "steps_per_block": args.steps, "clock": "HIP events, rank 0",

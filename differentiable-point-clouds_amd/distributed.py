@@ -81,3 +81,83 @@ def finalize():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+class GradBuckets(object):
+    """Bucketed gradient all-reduce that can be RECORDED: the parameters' .grad tensors are views into a few flat
+    buckets (filled in place by autograd), a post-accumulate hook per parameter counts its bucket down, and the
+    bucket's all-reduce is issued -- asynchronously, on the process group's own stream -- as soon as its last
+    gradient has landed, i.e. it overlaps with the rest of the backward pass exactly like DDP's reducer.  Unlike
+    DDP there is no host-side bookkeeping between steps (no reducer rebuild, no unused-parameter search), so the
+    whole step -- forward, backward, these collectives, the optimiser -- records into ONE HIP graph per rank
+    (RCCL collectives are stream work; torch records the fork / join of the communication stream as graph edges).
+
+        buckets = GradBuckets(net.parameters(), bucket_mb=64)      # once; every rank the same parameter order
+        loss.backward(); buckets.finish()                          # per step: grads are now the rank AVERAGE
+        optimizer.step(); buckets.zero_()                          # (never set_to_none: the views must survive)
+
+    Averaging matches DDP: sum over ranks, divided by the world size.  Works with any backend (the gloo tests
+    check it against a single process on the concatenated batch); with one rank it degenerates to plain
+    accumulation into the flat buffers."""
+
+    def __init__(self, params, bucket_mb=64, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        params = [p for p in params if p.requires_grad]
+        limit = int(bucket_mb * (1 << 20))
+        # buckets in REVERSE parameter order: the backward pass produces the last layers' gradients first
+        self.buckets, self._of = [], {}
+        cur, cur_bytes = [], 0
+        for p in reversed(params):
+            nbytes = p.numel() * p.element_size()
+            if cur and (cur_bytes + nbytes > limit or p.dtype != cur[0].dtype or p.device != cur[0].device):
+                self._close(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._close(cur)
+        self._pending = [0] * len(self.buckets)
+        self._works = []
+        for p in params:
+            p.register_post_accumulate_grad_hook(self._hook)
+        self._arm()
+
+    def _close(self, plist):
+        flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
+        off = 0
+        for p in plist:
+            piece = flat[off:off + p.numel()]
+            dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+            # same strides as the parameter (channels-last filters stay channels-last): autograd's layout contract
+            p.grad = piece.as_strided(p.shape, p.stride()) if dense else piece.view_as(p)
+            self._of[p] = len(self.buckets)
+            off += p.numel()
+        self.buckets.append((flat, list(plist)))
+
+    def _arm(self):
+        for i, (_, plist) in enumerate(self.buckets):
+            self._pending[i] = len(plist)
+
+    def _hook(self, p):
+        i = self._of[p]
+        self._pending[i] -= 1
+        if self._pending[i] == 0 and self.world > 1:
+            self._works.append(dist.all_reduce(self.buckets[i][0], group=self.group, async_op=True))
+
+    def finish(self):
+        """wait (stream-wise) for the bucket collectives and turn the sums into averages; re-arm for the next step"""
+        if self.world > 1:
+            for i, n in enumerate(self._pending):    # parameters that received no gradient this step: reduce anyway
+                if n > 0:
+                    self._works.append(dist.all_reduce(self.buckets[i][0], group=self.group, async_op=True))
+            for w in self._works:
+                w.wait()
+            for flat, _ in self.buckets:
+                flat.div_(self.world)
+        self._works = []
+        self._arm()
+
+    def zero_(self):
+        for flat, _ in self.buckets:
+            flat.zero_()

@@ -26,6 +26,8 @@ ProjMeta = collections.namedtuple(
 # ---------------------------------------------------------------------------
 def _lib_for(*tensors, dtypes=(torch.float32,)):
     lib = _capi.get_library()
+    host = lib.host_memory
+    dev = None
     for t in tensors:
         if t is None:
             continue
@@ -34,14 +36,15 @@ def _lib_for(*tensors, dtypes=(torch.float32,)):
         if t.dtype not in dtypes:
             raise TypeError("the projector computes in float32; got %s" % t.dtype if len(dtypes) == 1 else
                             "expected one of %s, got %s" % (dtypes, t.dtype))
-        if lib.host_memory:
+        if host:
             if t.is_cuda:
                 raise ValueError("emulation library needs host tensors")
         elif not t.is_cuda:
             raise ValueError("the HIP projector needs tensors on a ROCm device (no CPU fallback)")
-    devs = {t.device for t in tensors if t is not None}
-    if len(devs) > 1:
-        raise ValueError("tensors on different devices: %s" % sorted(map(str, devs)))
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError("tensors on different devices: %s" % sorted({str(x.device) for x in tensors if x is not None}))
     return lib
 
 
@@ -49,6 +52,13 @@ def _stream(lib, ref):
     if lib.host_memory:
         return None
     return ctypes.c_void_p(torch.cuda.current_stream(ref.device).cuda_stream)
+
+
+def _stream_int(lib, device):
+    """the current HIP stream of `device` as a plain integer (ctypes converts it to the void* argument)"""
+    if lib.host_memory:
+        return None
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def _p(t):
@@ -104,7 +114,8 @@ def _taps_of(taps):
             ts.append(None)
             ks.append(0)
             continue
-        t = _c(t).reshape(-1)
+        if t.dim() != 1 or not t.is_contiguous():
+            t = _c(t).reshape(-1)
         k = t.numel()
         if k % 2 != 1:
             raise ValueError("even Gaussian kernel sizes are not supported (TF pads them asymmetrically)")
@@ -144,6 +155,64 @@ class _Workspace(object):
         self.ptr = ctypes.c_void_p((base + 255) & ~255)
 
 
+def _a256(n):
+    return (n + 255) & ~255
+
+
+class _FusedPlan(object):
+    """Everything about one (library, B, N, grid, taps, collapse) combination that does not change from call to
+    call: the DpcShape struct, which buffers the library wants saved (dpc_saved_layout), their byte offsets inside
+    ONE arena allocation, and the workspace sizes.  ProjectFused runs every training step; asking the library
+    three questions and building ~10 tensors per call was most of its host time."""
+    __slots__ = ("shape", "shape_ref", "layout", "ws_fwd", "ws_bwd", "drc", "off_raw", "off_cmask", "off_pindex",
+                 "off_blur", "off_sums", "arena_bytes", "n_out")
+
+    def __init__(self, lib, B, N, meta, K):
+        self.shape = _shape(B, N, meta, K)
+        self.shape_ref = ctypes.byref(self.shape)
+        params = _params(meta._replace(l2_target=None, dropout_state=None))
+        self.layout = lib.dpc_saved_layout(self.shape_ref, ctypes.byref(params))
+        lib.check(min(self.layout, 0), "dpc_saved_layout")
+        self.ws_fwd = lib.dpc_workspace_bytes(self.shape_ref, 0)
+        self.ws_bwd = lib.dpc_workspace_bytes(self.shape_ref, 1)
+        self.drc = meta.collapse_mode == _capi.DPC_COLLAPSE_DRC
+        grid = 4 * B * meta.Dz * meta.D * meta.D
+        off = 0
+        self.off_raw = self.off_cmask = self.off_pindex = self.off_sums = -1
+        if self.layout & 1:                                   # generic path: the dense pre-clip grid
+            self.off_raw, off = off, off + _a256(grid)
+        if self.layout & 2:                                   # fused path: clip bytes ...
+            self.off_cmask, off = off, off + _a256(4 * B * N)
+        if self.layout & 4:                                   # ... and the depth-sorted point records
+            self.off_pindex, off = off, off + _a256(4 * lib.dpc_point_index_ints(self.shape_ref))
+        self.off_blur, off = off, off + _a256(grid)
+        if self.drc:
+            self.off_sums, off = off, off + _a256(16 * B * meta.D * meta.D)      # [B,D,D,2] float64
+        self.arena_bytes = off + 256
+        self.n_out = 2 if self.drc else 1                     # proj (+ proj_depth)
+
+
+_PLANS = {}
+
+
+def _fused_plan(lib, B, N, meta, K):
+    key = (id(lib), B, N, meta.Dz, meta.D, meta.collapse_mode, K)
+    plan = _PLANS.get(key)
+    if plan is None:
+        if len(_PLANS) > 256:
+            _PLANS.clear()
+        plan = _PLANS[key] = _FusedPlan(lib, B, N, meta, K)
+    return plan
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _at(base, off):
+    return None if off < 0 else base + off
+
+
 # ---------------------------------------------------------------------------
 # fused hot path
 # ---------------------------------------------------------------------------
@@ -152,7 +221,11 @@ class ProjectFused(torch.autograd.Function):
     focal) -> (proj [B,D,D,1], proj_depth [B,D,D,1] | None, tr_pc [B,N,3], l2_grad [B,D,D,1] | None).
     l2_grad (meta.l2_target set) = l2_weight * (proj - l2_target), written by the collapse kernel itself:
     the gradient of 0.5 * l2_weight * sum((proj - target)^2) w.r.t. proj, ready to be passed back as
-    grad_outputs; not differentiable."""
+    grad_outputs; not differentiable.
+
+    Host path: one cached plan per shape (_FusedPlan), three device allocations in forward (tr_pc; the images;
+    one arena for everything saved for backward -- the kernels take raw pointers, so the arena is never cut
+    into tensor views) plus the workspace, and pointers passed to ctypes as plain integers."""
 
     @staticmethod
     def forward(ctx, pc, pose, trans, scale, focal, tx, ty, tz, meta):
@@ -161,83 +234,88 @@ class ProjectFused(torch.autograd.Function):
         pc, pose, trans, scale, focal = _c(pc), _c(pose), _c(trans), _c(scale), _c(focal)
         (tx, ty, tz), K = _taps_of((tx, ty, tz))
         B, N = pc.shape[0], pc.shape[1]
-        Dz, D = meta.Dz, meta.D
-        new = lambda *s, **kw: _poison(torch.empty(*s, dtype=kw.get("dtype", torch.float32), device=pc.device))
-        l2_grad = None
-        if meta.l2_target is not None:
-            tgt = meta.l2_target
-            if meta.collapse_mode != _capi.DPC_COLLAPSE_DRC:
+        D = meta.D
+        dev = pc.device
+        plan = _fused_plan(lib, B, N, meta, K)
+        tgt = meta.l2_target
+        if tgt is not None:
+            if not plan.drc:
                 raise ValueError("the fused L2 epilogue lives in the DRC collapse kernel (ptn_max_projection is off it)")
             _lib_for(pc, tgt)
             if tgt.numel() != B * D * D or tuple(tgt.shape[:3]) != (B, D, D) or not tgt.is_contiguous():
                 raise ValueError("l2 target must be a contiguous [B,D,D] or [B,D,D,1] image, got %s for B=%d, D=%d"
                                  % (tuple(tgt.shape), B, D))
-            l2_grad = new(B, D, D, 1)
-        shape, params = _shape(B, N, meta, K), _params(meta, l2_grad)
-        tr_pc = new(B, N, 3)
-        layout = lib.dpc_saved_layout(ctypes.byref(shape), ctypes.byref(params))
-        lib.check(min(layout, 0), "dpc_saved_layout")
-        if meta.dropout_state is not None:
-            st = meta.dropout_state
-            if st.dtype != torch.int32 or st.numel() != 2 or not st.is_contiguous() or st.device != pc.device:
+        st = meta.dropout_state
+        if st is not None:
+            if st.dtype != torch.int32 or st.numel() != 2 or not st.is_contiguous() or st.device != dev:
                 raise ValueError("dropout state must be a contiguous int32 tensor {keep, seed} on the points' device")
-        if (0 < meta.dropout_keep < N or meta.dropout_state is not None) and not layout & 2:
+        if (0 < meta.dropout_keep < N or st is not None) and not plan.layout & 2:
             raise ValueError("fused point dropout needs the fused path (power-of-two vox_size in [32,256], kernel size "
                              "5/11/21, vox_size_z <= 256); use pc_point_dropout for this shape")
-        grid_raw = new(B, Dz, D, D) if layout & 1 else None
-        clip_mask = new(B, N, 4, dtype=torch.uint8) if layout & 2 else None
-        point_index = new(lib.dpc_point_index_ints(ctypes.byref(shape)), dtype=torch.int32) if layout & 4 else None
-        grid_blur = new(B, Dz, D, D)
-        drc = meta.collapse_mode == _capi.DPC_COLLAPSE_DRC
-        logt = new(B, D, D, 2, dtype=torch.float64) if drc else None
-        proj = new(B, D, D, 1)
-        depth = new(B, D, D, 1) if drc else None
-        ws = _Workspace(lib, shape, 0, pc)
-        rc = lib.dpc_project_forward(_stream(lib, pc), ctypes.byref(shape), ctypes.byref(params),
-                                     _p(pc), _p(pose), _p(trans), _p(scale), _p(focal),
-                                     _p(tx), _p(ty), _p(tz), _p(tr_pc), _p(grid_raw), _p(clip_mask),
-                                     _p(point_index), _p(grid_blur), _p(logt), _p(proj), _p(depth), ws.ptr, ws.nbytes)
+        n_img = plan.n_out + (1 if tgt is not None else 0)
+        imgs = torch.empty(n_img, B, D, D, 1, dtype=torch.float32, device=dev)      # proj | proj_depth | l2_grad
+        tr_pc = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+        arena = torch.empty(plan.arena_bytes, dtype=torch.uint8, device=dev)
+        work = torch.empty(plan.ws_fwd + 256, dtype=torch.uint8, device=dev)
+        if _POISON:
+            imgs.fill_(float("nan"))
+            tr_pc.fill_(float("nan"))
+            arena.fill_(255)                   # 0xffffffff is a NaN, 0xff..ff a NaN double
+            work.fill_(255)
+        views = imgs.unbind(0)
+        proj = views[0]
+        depth = views[1] if plan.drc else None
+        l2_grad = views[plan.n_out] if tgt is not None else None
+        params = _params(meta, l2_grad)
+        base = _a256(arena.data_ptr())
+        rc = lib.dpc_project_forward(_stream_int(lib, dev), plan.shape_ref, ctypes.byref(params),
+                                     pc.data_ptr(), pose.data_ptr(), _ptr(trans), _ptr(scale), _ptr(focal),
+                                     _ptr(tx), _ptr(ty), _ptr(tz), tr_pc.data_ptr(), _at(base, plan.off_raw),
+                                     _at(base, plan.off_cmask), _at(base, plan.off_pindex), base + plan.off_blur,
+                                     _at(base, plan.off_sums), proj.data_ptr(), _ptr(depth),
+                                     _a256(work.data_ptr()), plan.ws_fwd)
         lib.check(rc, "dpc_project_forward")
-        ctx.meta, ctx.K = meta, K
+        ctx.meta, ctx.K, ctx.plan = meta, K, plan
         ctx.set_materialize_grads(False)     # unused outputs (depth, tr_pc) arrive as None, not as zero fills
-        ctx.has = (trans is not None, scale is not None, focal is not None)
         ctx.scale_shape = None if scale is None else tuple(scale.shape)
         ctx.focal_shape = None if focal is None else tuple(focal.shape)
-        ctx.save_for_backward(pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, grid_raw, clip_mask, point_index,
-                              grid_blur, logt)
+        ctx.save_for_backward(pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, arena)
         if l2_grad is not None:
             ctx.mark_non_differentiable(l2_grad)
         return proj, depth, tr_pc, l2_grad
 
     @staticmethod
     def backward(ctx, dproj, ddepth, dtr, _dl2=None):
-        (pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, grid_raw, clip_mask, point_index, grid_blur,
-         logt) = ctx.saved_tensors
-        meta = ctx.meta._replace(l2_target=None)
+        pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, arena = ctx.saved_tensors
+        plan = ctx.plan
+        meta = ctx.meta
         lib = _lib_for(pc)
         B, N = pc.shape[0], pc.shape[1]
-        shape, params = _shape(B, N, meta, ctx.K), _params(meta)
+        dev = pc.device
+        params = _params(meta if meta.l2_target is None else meta._replace(l2_target=None))
         dproj, ddepth, dtr = _c(dproj), _c(ddepth), _c(dtr)
-        if dproj is None and ddepth is None:
-            dproj = torch.zeros(B, meta.D, meta.D, 1, dtype=torch.float32, device=pc.device)
-        if meta.collapse_mode != _capi.DPC_COLLAPSE_DRC:
+        if not plan.drc:
             ddepth = None
-            if dproj is None:
-                dproj = torch.zeros(B, meta.D, meta.D, 1, dtype=torch.float32, device=pc.device)
-        new = lambda *s: _poison(torch.empty(*s, dtype=torch.float32, device=pc.device))
+        if dproj is None and ddepth is None:
+            dproj = torch.zeros(B, meta.D, meta.D, 1, dtype=torch.float32, device=dev)
+        new = lambda *s: _poison(torch.empty(*s, dtype=torch.float32, device=dev))
         dpc = new(B, N, 3)
-        dpose = torch.empty_like(pose)
+        dpose = _poison(torch.empty_like(pose))
         dtrans = new(B, 3) if trans is not None else None
         dscale = new(B) if scale is not None else None
         # the matrix branch never reads the per-instance focal length (point_cloud.py:191-205): no gradient
         dfocal = new(B) if (focal is not None and meta.pose_quaternion) else None
-        ws = _Workspace(lib, shape, 1, pc)
-        rc = lib.dpc_project_backward(_stream(lib, pc), ctypes.byref(shape), ctypes.byref(params),
-                                      _p(pc), _p(pose), _p(trans), _p(scale), _p(focal),
-                                      _p(tx), _p(ty), _p(tz), _p(tr_pc), _p(grid_raw), _p(clip_mask),
-                                      _p(point_index), _p(grid_blur), _p(logt), _p(dproj), _p(ddepth), _p(dtr),
-                                      _p(dpc), _p(dpose), _p(dtrans), _p(dscale), _p(dfocal),
-                                      ws.ptr, ws.nbytes)
+        work = torch.empty(plan.ws_bwd + 256, dtype=torch.uint8, device=dev)
+        if _POISON:
+            work.fill_(255)
+        base = _a256(arena.data_ptr())
+        rc = lib.dpc_project_backward(_stream_int(lib, dev), plan.shape_ref, ctypes.byref(params),
+                                      pc.data_ptr(), pose.data_ptr(), _ptr(trans), _ptr(scale), _ptr(focal),
+                                      _ptr(tx), _ptr(ty), _ptr(tz), tr_pc.data_ptr(), _at(base, plan.off_raw),
+                                      _at(base, plan.off_cmask), _at(base, plan.off_pindex), base + plan.off_blur,
+                                      _at(base, plan.off_sums), _ptr(dproj), _ptr(ddepth), _ptr(dtr),
+                                      dpc.data_ptr(), dpose.data_ptr(), _ptr(dtrans), _ptr(dscale), _ptr(dfocal),
+                                      _a256(work.data_ptr()), plan.ws_bwd)
         lib.check(rc, "dpc_project_backward")
         if dscale is not None:
             dscale = dscale.reshape(ctx.scale_shape)

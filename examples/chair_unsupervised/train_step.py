@@ -12,8 +12,9 @@ images/masks, random-init weights.  Mirrors experiments/chair_unsupervised
 Data parallel over MODELS: each rank owns batch_size models and replicates
 them over views / candidates locally, so the [B,N,3] replication never crosses
 xGMI; the only exchange is DDP's bucketed all-reduce of the ~33 M parameter
-gradients (backend "nccl" = RCCL).  The loss is normalised by the GLOBAL
-number of samples so that DDP's gradient averaging reproduces the 1-GPU step
+gradients (backend "nccl" = RCCL).  Every rank normalises the loss by its
+LOCAL number of samples; averaging the gradients over ranks (DDP, or the
+recordable GradBuckets reducer under --graph) then reproduces the 1-GPU step
 on the concatenated batch.
 """
 import argparse
@@ -52,16 +53,26 @@ def synthetic_batch(cfg, device, image_size, seed):
     return {"images": images, "masks": masks}
 
 
-def train_step(net, projector, inputs, optimizer, world=1, is_training=True):
+def train_step(net, projector, inputs, optimizer, world=1, is_training=True, buckets=None):
+    """One optimiser step.  `buckets` (dpc_amd.distributed.GradBuckets over the parameters of an UNWRAPPED net):
+    the gradient all-reduce is issued per bucket from inside the backward pass and waited for before the
+    optimiser -- the recordable alternative to DistributedDataParallel (whole step in one HIP graph per rank)."""
     cfg = projector.cfg()
     outputs = net(inputs["images"])
     outputs = projector.replicate_outputs(outputs)
     outputs = projector.compute_projection(inputs, outputs, is_training=is_training)
+    # add_proj_loss normalises by the LOCAL sample count of this rank; the gradient AVERAGE over ranks (DDP, or
+    # GradBuckets.finish) then equals the single-process gradient on the concatenated batch
     loss = projector.add_proj_loss(inputs, outputs, cfg.proj_weight)
-    # add_proj_loss divides by the LOCAL sample count; DDP averages over ranks => global normalisation
-    optimizer.zero_grad(set_to_none=True)
-    loss.backward()
-    optimizer.step()
+    if buckets is None:
+        optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        optimizer.step()
+    else:
+        loss.backward()                 # the buckets were zeroed by the previous step (or at construction)
+        buckets.finish()
+        optimizer.step()
+        buckets.zero_()
     return loss.detach()
 
 
@@ -78,7 +89,8 @@ def main():
     ap.add_argument("--max-steps", type=int, default=1000, help="length of the schedules (cfg.max_number_of_steps)")
     ap.add_argument("--graph", action="store_true",
                     help="record the whole step (nets, projector, loss, backward, Adam) into one HIP graph and replay it; "
-                         "the schedules and the dropout draw keep moving (ModelPointCloud.enable_graph_replay). 1 GPU.")
+                         "the schedules and the dropout draw keep moving (ModelPointCloud.enable_graph_replay).  With "
+                         "--gpus N the gradient all-reduce is part of the recorded step (GradBuckets instead of DDP).")
     args = ap.parse_args()
     dd = dpc_amd.distributed
     rank, world, device = dd.init("nccl")
@@ -89,18 +101,18 @@ def main():
                    **({} if args.scheduled else {"pc_relative_sigma_end": 3.0}))
     torch.manual_seed(0)
     net = Im2PointCloud(cfg, args.image_size).to(device)
-    model = net
-    if world > 1:
+    model, buckets = net, None
+    if world > 1 and args.graph:
+        buckets = dd.GradBuckets(net.parameters(), bucket_mb=64)       # recordable bucketed all-reduce (no DDP wrapper)
+    elif world > 1:
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[device.index], bucket_cap_mb=64,
                                                           gradient_as_bucket_view=True)
     projector = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device=device)
     torch.backends.cudnn.benchmark = True          # MIOpen find mode for the stock convolutions
     opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=args.graph, fused=True)
     inputs = synthetic_batch(cfg, device, args.image_size, seed=rank)
-    run = lambda: train_step(model, projector, inputs, opt, world)
+    run = lambda: train_step(model, projector, inputs, opt, world, buckets=buckets)
     if args.graph:
-        if world > 1:
-            raise SystemExit("--graph is single-GPU (DDP's bucketed all-reduce is not captured here)")
         projector.enable_graph_replay()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

@@ -50,6 +50,24 @@ def test_config_3_ddp_training_step_self_launches(emu_library):
     assert j["value"] > 0 and j["steps_per_s"] > 0
 
 
+def test_strong_scaling_splits_the_global_batch(emu_library):
+    """SURVEY.md 8(e) secondary mode: the config's batch split over the ranks (here 2 views -> 1 per rank)."""
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--scaling", "strong"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["global_batch"] == 2
+
+
+def test_config_3_graph_mode_uses_the_recordable_reducer(emu_library):
+    """`bench.py --gpus 2 --config 3 --graph`: the gradient all-reduce comes from GradBuckets (hooks inside the
+    backward pass) instead of DDP, so that a GPU run can record the whole step; under gloo it runs eagerly."""
+    r = _run(["--gpus", "2", "--config", "3", "--graph", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and "GradBuckets" in j["config"]["parallelism"] and j["config"]["hip_graph"] is False
+    assert "dry run" in j["config"]["hip_graph_note"] and j["value"] > 0
+
+
 def test_gpus_1_runs_in_process(emu_library):
     r = _run(["--steps", "2", "--warmup", "1"])
     assert r.returncode == 0, r.stderr[-2000:]

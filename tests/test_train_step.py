@@ -19,16 +19,20 @@ def _toy_cfg(ts, models):
                        step_size=2, batch_size=models, pc_point_dropout=1.0)
 
 
-def _grads(ts, nets, cfg, images, masks, world=1, ddp=False):
+def _grads(ts, nets, cfg, images, masks, world=1, ddp=False, buckets=False):
     import dpc_amd
     torch.manual_seed(0)
     net = nets.Im2PointCloud(cfg, image_size=32, f_dim=4, fc_dim=32, z_dim=32)
     model = torch.nn.parallel.DistributedDataParallel(net) if ddp else net
+    red = dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=0.05) if buckets else None   # several buckets
     proj = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device="cpu")
     outputs = proj.replicate_outputs(model(images))
     outputs = proj.compute_projection({"masks": masks}, outputs, is_training=False)
     loss = proj.add_proj_loss({"masks": masks}, outputs, 1.0)
     loss.backward()
+    if red is not None:
+        assert len(red.buckets) > 2
+        red.finish()
     return {n: p.grad.clone() for n, p in net.named_parameters()}, float(loss)
 
 
@@ -54,8 +58,11 @@ def _worker(rank, world, port, ret):
     images, masks = _data(4)
     lo, hi = dpc_amd.distributed.shard_range(4, rank, world)        # shard over MODELS
     g, loss = _grads(ts, nets, _toy_cfg(ts, hi - lo), images[2 * lo:2 * hi], masks[2 * lo:2 * hi], world, ddp=True)
+    # the recordable reducer (what bench.py --config 3 --graph --gpus N and train_step.py --graph use instead of DDP)
+    gb, _ = _grads(ts, nets, _toy_cfg(ts, hi - lo), images[2 * lo:2 * hi], masks[2 * lo:2 * hi], world, buckets=True)
     if rank == 0:
         ret["grads"] = {k: v.numpy() for k, v in g.items()}
+        ret["grads_buckets"] = {k: v.numpy() for k, v in gb.items()}
     dpc_amd.distributed.finalize()
 
 
@@ -77,6 +84,33 @@ def test_training_step_runs_and_ddp_matches_single_process(emu):
     for k, v in ref.items():
         a, b = ret["grads"][k], v.numpy()
         assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max()), k
+        a = ret["grads_buckets"][k]                  # GradBuckets: same averages as DDP
+        assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max()), k
+
+
+def test_grad_buckets_step_equals_plain_step(emu):
+    """train_step(buckets=...) on one rank: gradients accumulate into the flat buckets in place, Adam steps on
+    the views, the buckets are zeroed for the next step -- two steps give the same parameters as the plain path."""
+    for p in (ROOT, EX):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import dpc_amd
+    import nets
+    import train_step as ts
+    cfg = _toy_cfg(ts, 2)
+    images, masks = _data(2)
+    finals = []
+    for use_buckets in (False, True):
+        torch.manual_seed(0)
+        net = nets.Im2PointCloud(cfg, image_size=32, f_dim=4, fc_dim=32, z_dim=32)
+        proj = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device="cpu")
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        red = dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=0.05) if use_buckets else None
+        for _ in range(2):
+            ts.train_step(net, proj, {"images": images, "masks": masks}, opt, is_training=False, buckets=red)
+        finals.append({n: p.detach().clone() for n, p in net.named_parameters()})
+    for k in finals[0]:
+        assert torch.allclose(finals[0][k], finals[1][k], rtol=0, atol=1e-6), k
 
 
 def test_optimizer_step_changes_parameters(emu):
