@@ -161,21 +161,25 @@ static inline float __shfl_xor(float v, int mask, int width = 64) {
   return r;
 }
 
-// DPP row shifts (v_mov_b32 dpp row_shl:n / row_shr:n, the controls the kernels use): rows of 16 lanes;
+// DPP row shifts and row broadcasts (v_mov_b32 dpp row_shl:n / row_shr:n / row_bcast:15 / row_bcast:31, the controls the
+// kernels use): rows of 16 lanes;
 // row_shr:n -- lane i reads lane i-n, row_shl:n -- lane i reads lane i+n; a lane without a source inside
 // its row gets 0 (bound_ctrl) or keeps `old`.  Lane mapping verified on MI355X (scripts/ubench/dpp_check.hip).
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
-  (void)row_mask; (void)bank_mask;
+  (void)bank_mask;
   unsigned f = hipemu::t_ctx.flat;
   memcpy(&hipemu::g_xchg[f], &src, 4);
   hipemu::wave_sync();
-  const int lane = (int)(f & 63u), r = lane & 15;
+  const int lane = (int)(f & 63u), r = lane & 15, row = lane >> 4;
   int from = -1;
   if (ctrl >= 0x101 && ctrl <= 0x10f) from = (r + (ctrl - 0x100) < 16) ? lane + (ctrl - 0x100) : -1;
   else if (ctrl >= 0x111 && ctrl <= 0x11f) from = (r - (ctrl - 0x110) >= 0) ? lane - (ctrl - 0x110) : -1;
+  else if (ctrl == 0x142) from = row >= 1 ? 16 * row - 1 : -1;     // row_bcast:15: lane 15 of the previous row
+  else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;               // row_bcast:31: lane 31 to rows 2 and 3
   else abort();
   unsigned nthreads = hipemu::t_ctx.bdim.x * hipemu::t_ctx.bdim.y * hipemu::t_ctx.bdim.z;
   int res = bound_ctrl ? 0 : old;
+  if (!((row_mask >> row) & 1)) from = -1, res = old;              // rows outside row_mask keep `old`
   if (from >= 0 && (f & ~63u) + (unsigned)from < nthreads) memcpy(&res, &hipemu::g_xchg[(f & ~63u) + (unsigned)from], 4);
   hipemu::wave_sync();
   return res;
