@@ -97,7 +97,7 @@ class ModelPointCloud(object):
         if self._device is None or torch.device(self._device).type != "cuda":
             raise ValueError("graph replay needs the projector on a ROCm device")
         self._graph_replay = True
-        seed = (torch.initial_seed() * 1103515245 + 12345) & 0x7fffffff
+        seed = ((torch.initial_seed() ^ self._rank_salt()) * 1103515245 + 12345) & 0x7fffffff
         self._dropout_seed64 = torch.tensor([seed], dtype=torch.int64, device=self._device)
         self._dropout_state = torch.zeros(2, dtype=torch.int32, device=self._device)
         self._dropout_state[1:2].copy_(self._dropout_seed64)
@@ -108,6 +108,9 @@ class ModelPointCloud(object):
         keep = cfg.pc_num_points
         if cfg.pc_point_dropout != 1:
             keep = int(cfg.pc_num_points * float(self.get_dropout_keep_prob()))
+        if keep < 1:
+            raise ValueError("point dropout would keep int(%d * %g) = 0 points (the kernels read keep = 0 as 'dropout off')"
+                             % (cfg.pc_num_points, self.get_dropout_keep_prob()))
         self._dropout_state[0:1].fill_(keep)          # the scalar travels as a kernel argument: no host buffer to race on
 
     def _advance_dropout_state(self):
@@ -139,11 +142,21 @@ class ModelPointCloud(object):
         K = tuple(0 if t is None else int(t.numel()) for t in taps)
         return ops.uses_fused_path(ops._capi.get_library(), all_points.shape[0], all_points.shape[1], _meta(cfg), K)
 
+    @staticmethod
+    def _rank_salt():
+        """Every rank of a data-parallel job seeds torch alike (torch.manual_seed(0) in the training scripts); the
+        reference's per-process np.random draws are independent across workers, so the rank is folded into the
+        dropout's seed stream (0 for a single process)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return ((dist.get_rank() + 1) * 0x9E3779B1) & 0x7fffffff
+        return 0
+
     def _next_dropout_seed(self):
         """One 32-bit seed per step from a host-side LCG started at torch's seed: no device work, no sync."""
         s = getattr(self, "_dropout_seed", None)
         if s is None:
-            s = torch.initial_seed() & 0xffffffff
+            s = (torch.initial_seed() ^ self._rank_salt()) & 0xffffffff
         s = (s * 1664525 + 1013904223) & 0xffffffff
         self._dropout_seed = s
         return s
@@ -199,6 +212,11 @@ class ModelPointCloud(object):
                 else:
                     point_dropout = (int(all_points.shape[1] * float(keep_prob)), self._next_dropout_seed())
             else:
+                if getattr(self, "_graph_replay", False):
+                    # the explicit gather bakes int(N * keep_prob) into tensor SHAPES: a recorded step would replay
+                    # the keep probability of the capture for ever
+                    raise NotImplementedError("graph replay with point dropout needs the fused draw (fast projector's "
+                                              "fused path, no colour channels, no drc loss)")
                 all_points, all_rgb = pc_point_dropout(all_points, all_rgb, keep_prob)
         if cfg.pc_fast:
             predicted_translation = outputs["predicted_translation"] if cfg.predict_translation else None
@@ -260,6 +278,10 @@ class ModelPointCloud(object):
         if gt_size > pred_size and cfg.bicubic_gt_downsampling:
             raise NotImplementedError("bicubic GT downsampling")
         if cfg.pc_gauss_filter_gt:                                          # model_pc.py:398-404
+            if getattr(self, "_graph_replay", False):
+                # the GT blur takes sigma as a host number and a host branch on it: a recorded step would freeze both
+                raise NotImplementedError("graph replay with pc_gauss_filter_gt (the annealed sigma reaches the GT "
+                                          "blur as a host scalar)")
             if gt_size > pred_size:
                 gt = resize_images_bilinear_tf1(gt, [pred_size, pred_size])
             smoothed = gauss_smoothen_image(cfg, gt, self._sigma_rel)

@@ -23,11 +23,6 @@ def _meta(cfg, Dz, D, collapse=_capi.DPC_COLLAPSE_DRC):
                         collapse_mode=collapse)
 
 
-def _check_cfg(cfg):
-    """Every drc_* switch of the reference maps onto the same kernels (see the module docstring)."""
-    return None
-
-
 def _grid4(voxels):
     if voxels.dim() == 5:
         if voxels.shape[-1] != 1:
@@ -40,7 +35,6 @@ def _grid4(voxels):
 
 def drc_event_probabilities_impl(voxels, cfg, flip_h=False):
     """dpc/util/drc.py:47-102.  Returns (p, proj) both with a trailing 1."""
-    _check_cfg(cfg)
     v = _grid4(voxels)
     proj, p = ops.DrcProjection.apply(v, _meta(cfg, v.shape[1], v.shape[2]), 1 if flip_h else 0)
     return p.unsqueeze(-1), proj.unsqueeze(-1)

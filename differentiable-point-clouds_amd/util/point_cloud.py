@@ -209,7 +209,6 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
     0.5 * weight * sum((proj - gt)^2) w.r.t. ``proj`` -- pass it to backward as the gradient of ``proj``
     (``torch.autograd.grad(out["proj"], inputs, out["proj_l2_grad"])``); gt is [B,D,D] or [B,D,D,1] at the
     projection's own size."""
-    _drc._check_cfg(cfg)
     meta = _meta(cfg)
     if point_dropout is not None:
         if all_rgb is not None:
@@ -217,6 +216,10 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
         if isinstance(point_dropout, torch.Tensor):
             meta = meta._replace(dropout_state=point_dropout)
         else:
+            if int(point_dropout[0]) < 1:
+                # the reference keeps int(N * keep_prob) points -- an empty cloud when that is 0; the kernels read
+                # keep = 0 as "dropout off", so the caller's intent cannot be honoured silently
+                raise ValueError("point_dropout would keep %d points" % int(point_dropout[0]))
             meta = meta._replace(dropout_keep=int(point_dropout[0]), dropout_seed=int(point_dropout[1]) & 0xffffffff)
     if l2_target is not None:
         meta = meta._replace(l2_target=l2_target[0].detach(), l2_weight=float(l2_target[1]))

@@ -109,6 +109,7 @@ def _nudge_off_cell_faces(inp, trans, focal, Dz, D, tol=3e-5):
     Points involved in either coincidence are moved a little (0.3 %), until none is left."""
     f64 = lambda a: None if a is None else a.astype(np.float64)
     pc = inp["pc"].copy()
+    moved = np.zeros(pc.shape[:2], dtype=bool)
     size = np.array([Dz - 1, D - 1, D - 1], dtype=np.float64)
     for _ in range(12):
         tr = onp.transform_fwd(f64(pc), f64(inp["pose"]), f64(trans), f64(focal))
@@ -125,7 +126,9 @@ def _nudge_off_cell_faces(inp, trans, focal, Dz, D, tol=3e-5):
         if not bad.any():
             break
         pc[bad] *= np.float32(1.003)
+        moved |= bad
     inp["pc"] = pc
+    inp["moved_points"] = int(moved.sum())          # callers assert / report how many inputs were touched
     return inp
 
 
@@ -426,7 +429,9 @@ def fused_dropout_equals_explicit_subset(dev, B=3, N=420, D=32, K=5, keep=137, s
     assert relerr(g[1].cpu().numpy(), rg[1].cpu().numpy()) < 1e-5
     assert relerr(g[2].cpu().numpy(), rg[2].cpu().numpy()) < 1e-5
     assert out["tr_pc"].shape == (B, N, 3)
-    # keep >= N and keep == 0 mean "no dropout"
+    # keep >= N means "no dropout"; keep == 0 (an empty cloud in the reference, "off" to the kernels) is refused
+    with pytest.raises(ValueError):
+        dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale, point_dropout=(0, 1))
     full = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale, point_dropout=(N, 1))
     plain = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale)
     assert float((full["proj"] - plain["proj"]).abs().max()) == 0.0
@@ -620,3 +625,70 @@ def degenerate_clouds_against_numpy_oracle(dev, heavy=True):
             assert abs(float(out["proj"].max()) - float(out["proj"].min())) == 0.0       # every ray is the empty ray
         if name == "pile":
             assert float(g[0].abs().max()) == 0.0       # G0 = 300 x weight >> 1 at all 8 corners: the clip blocks everything
+
+
+# ---------------------------------------------------------------------------
+# round-3 cases
+# ---------------------------------------------------------------------------
+def fused_dropout_kept_mask_from_library(dev, pc_np, pose_np, D, K, keep, seed, sigma=0.9):
+    """White-box read of the fused dropout's draw: run dpc_project_forward through the C ABI on caller-allocated
+    buffers and decode point_index -- a point was kept (and is inside the cube) iff its slot lies below the start
+    of the "dropped" bucket.  Returns a [B, N] bool array."""
+    import ctypes
+    lib = dpc_amd.get_library()
+    B, N = pc_np.shape[0], pc_np.shape[1]
+    cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K)
+    kern = dpc_amd.smoothing_kernel(cfg, sigma, device=dev)
+    taps = [k.reshape(-1).contiguous() for k in kern]
+    S = dpc_amd._capi.DpcShape(B, N, D, D, K, K, K)
+    P = dpc_amd._capi.DpcParams(2.0, 1.875, 1e-5, 10.0, 1, 0, 0, int(keep), int(seed) & 0xffffffff)
+    assert lib.dpc_saved_layout(ctypes.byref(S), ctypes.byref(P)) & 6 == 6, "expected the fused path"
+    t = lambda a: torch.tensor(a, device=dev)
+    pc, pose = t(pc_np), t(pose_np)
+    new = lambda *s, **k: torch.empty(*s, device=dev, dtype=k.get("dtype", torch.float32))
+    tr_pc, cmask = new(B, N, 3), new(B, N, 4, dtype=torch.uint8)
+    pindex = new(lib.dpc_point_index_ints(ctypes.byref(S)), dtype=torch.int32)
+    blur, sums, proj, depth = new(B, D, D, D), new(B, D, D, 2, dtype=torch.float64), new(B, D, D), new(B, D, D)
+    nws = lib.dpc_workspace_bytes(ctypes.byref(S), 0)
+    ws = torch.empty(nws + 256, dtype=torch.uint8, device=dev)
+    p = lambda x: None if x is None else ctypes.c_void_p(x.data_ptr())
+    stream = None if lib.host_memory else ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.dpc_project_forward(stream, ctypes.byref(S), ctypes.byref(P), p(pc), p(pose), None, None, None,
+                                 p(taps[0]), p(taps[1]), p(taps[2]), p(tr_pc), None, p(cmask), p(pindex), p(blur), p(sums),
+                                 p(proj), p(depth), ctypes.c_void_p((ws.data_ptr() + 255) & ~255), nws)
+    lib.check(rc, "dpc_project_forward")
+    pi = pindex.cpu().numpy()
+    slot_of = pi[4 * B * N:5 * B * N].reshape(B, N)
+    zstart = pi[5 * B * N:5 * B * N + B * (D + 2)].reshape(B, D + 2)
+    return slot_of < zstart[:, D:D + 1]
+
+
+def dropout_statistics(masks, keep, pairs):
+    """Inclusion and pair-inclusion statistics of a stack of draws masks [K, N] (bool; row = one (seed, instance)
+    key, exactly `keep` true entries): z-scores against sampling without replacement, as chi-squares.
+    Returns dict(chi_incl, df_incl, zmax_incl, chi_pair, df_pair, zmax_pair)."""
+    Kk, N = masks.shape
+    assert (masks.sum(1) == keep).all()
+    p = keep / N
+    cnt = masks.sum(0).astype(np.float64)
+    z = (cnt - Kk * p) / np.sqrt(Kk * p * (1 - p))
+    p2 = keep * (keep - 1) / (N * (N - 1))
+    both = (masks[:, pairs[:, 0]] & masks[:, pairs[:, 1]]).sum(0).astype(np.float64)
+    z2 = (both - Kk * p2) / np.sqrt(Kk * p2 * (1 - p2))
+    return dict(chi_incl=float((z ** 2).sum()), df_incl=N - 1, zmax_incl=float(np.abs(z).max()),
+                chi_pair=float((z2 ** 2).sum()), df_pair=len(pairs), zmax_pair=float(np.abs(z2).max()))
+
+
+def dropout_pairs(N, rng, nrandom=4000):
+    """index pairs whose joint inclusion is tested: random ones, neighbours (n, n+1), and a stride of 64 (one wave)"""
+    r = np.stack([rng.integers(0, N, nrandom), rng.integers(0, N, nrandom)], 1)
+    r = r[r[:, 0] != r[:, 1]]
+    return np.concatenate([r, np.stack([np.arange(N - 1), np.arange(1, N)], 1),
+                           np.stack([np.arange(N - 64), np.arange(64, N)], 1)])
+
+
+def assert_dropout_statistics(st, sigmas=5.0, zmax=6.0):
+    for tag in ("incl", "pair"):
+        chi, df = st["chi_" + tag], st["df_" + tag]
+        assert abs(chi - df) < sigmas * np.sqrt(2.0 * df), (tag, st)
+        assert st["zmax_" + tag] < zmax, (tag, st)
