@@ -38,7 +38,7 @@ class DpcParams(ctypes.Structure):
                 ("pose_is_quaternion", ctypes.c_int32), ("collapse_mode", ctypes.c_int32),
                 ("flags", ctypes.c_int32), ("dropout_keep", ctypes.c_int32), ("dropout_seed", ctypes.c_uint32),
                 ("dropout_state", ctypes.c_void_p), ("l2_target", ctypes.c_void_p), ("l2_grad", ctypes.c_void_p),
-                ("l2_weight", ctypes.c_float)]
+                ("l2_weight", ctypes.c_float), ("views_per_cloud", ctypes.c_int32)]
 
 
 _P = ctypes.c_void_p

@@ -198,7 +198,7 @@ size_t dpc_workspace_bytes(const DpcShape* shape, int direction) {
   if (check_shape(shape, false) != DPC_OK) return 0;
   const size_t g = align256(grid_elems(*shape) * sizeof(float));
   const size_t acc = align256(sizeof(float) * 16 * (size_t)shape->B);
-  return direction == 0 ? g : 2 * g + acc + parts_bytes(*shape) + dsparts_bytes(*shape);
+  return direction == 0 ? g : 2 * g + acc + parts_bytes(*shape) + dsparts_bytes(*shape) + dpc_views_bytes(*shape);
 }
 
 int dpc_transform_fwd(dpc_stream_t stream, const DpcShape* shape, const DpcParams* params, const float* pc,
@@ -360,6 +360,7 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   if (P.l2_target && !drc) return DPC_E_MODE;   // the L2 epilogue lives in the DRC collapse kernel
   if (P.l2_target && !P.l2_grad) return DPC_E_NULL;
   const SplatPlan plan = splat_plan(S);
+  if (P.views_per_cloud > 1 && (!plan.ok || S.B % P.views_per_cloud != 0)) return DPC_E_MODE;   // replication lives in the fused path's kernels
   if (plan.ok ? (!clip_mask || !point_index) : !grid_raw) return DPC_E_NULL;
   if (plan.ok && ((uintptr_t)point_index & 15) != 0) return DPC_E_WORKSPACE;   // 16-byte point records
   // the fused dropout lives in the depth sort of the fused path: refuse rather than silently keep every point
@@ -457,6 +458,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   if (!dproj && !(drc && dproj_depth)) return DPC_E_NULL;
   if (scale && !dscale) return DPC_E_NULL;
   const SplatPlan plan = splat_plan(S);
+  if (P.views_per_cloud > 1 && (!plan.ok || S.B % P.views_per_cloud != 0)) return DPC_E_MODE;
   const bool use_cmask = plan.ok;
   if (use_cmask ? (!clip_mask || !point_index) : !grid_raw) return DPC_E_NULL;
   if (use_cmask && ((uintptr_t)point_index & 15) != 0) return DPC_E_WORKSPACE;
@@ -508,10 +510,23 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
     // then the camera-transform VJP over the per-slot partials
     rc = launch_gather_yx(st, S, plan, tA, pi, clip_mask, taps_x, taps_y, parts);
     if (rc) return rc;
-    return launch_points_bwd_sorted(st, S, P, pc, pose, trans, focal, tr_pc, pi, dtr_pc_in, parts,
-                                    plan.nstrips == 1 ? 2 : 4, dpc, dpose, dtrans,
-                                    dfocal, scale ? dscale : nullptr, accum, (zfused && scale) ? dsparts : nullptr,
-                                    nzb);
+    // clouds replicated inside the kernels: per-instance point gradients go to the workspace, their sum over a
+    // cloud's instances to the caller's dpc [B / R, N, 3]
+    const int R = P.views_per_cloud > 1 ? P.views_per_cloud : 1;
+    float* dpc_views = R > 1 ? (float*)((char*)dsparts + dsparts_bytes(S)) : dpc;
+    rc = launch_points_bwd_sorted(st, S, P, pc, pose, trans, focal, tr_pc, pi, dtr_pc_in, parts,
+                                  plan.nstrips == 1 ? 2 : 4, dpc_views, dpose, dtrans,
+                                  dfocal, scale ? dscale : nullptr, accum, (zfused && scale) ? dsparts : nullptr,
+                                  nzb);
+    if (rc || R == 1) return rc;
+    const int L = 3 * S.N;
+    if (L % 4 == 0)
+      DPC_LAUNCH("sum_views", (k_sum_views<4>), dim3((L / 4 + DPC_BLOCK - 1) / DPC_BLOCK, S.B / R, 1), dim3(DPC_BLOCK, 1, 1), 0,
+                 st, (const float*)dpc_views, dpc, R, L);
+    else
+      DPC_LAUNCH("sum_views", (k_sum_views<1>), dim3((L + DPC_BLOCK - 1) / DPC_BLOCK, S.B / R, 1), dim3(DPC_BLOCK, 1, 1), 0, st,
+                 (const float*)dpc_views, dpc, R, L);
+    return last_error();
   }
   // 2. y-blur adjoint (dense) -> tB ; the x-blur is evaluated sparsely in step 3
   const float* dg = tA;

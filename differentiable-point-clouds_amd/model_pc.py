@@ -27,6 +27,45 @@ def tf_repeat_0(input, num):  # noqa: A002  (reference name; model_pc.py:23-32)
     return torch.repeat_interleave(input, int(num), dim=0)
 
 
+class ReplicatedOutputs(dict):
+    """The `outputs` dict after the replication block of get_model_fn (model_pc.py:270-299).  ``all_points`` --
+    the [B * views * candidates, N, 3] copy of every predicted cloud -- is built on first access only: the fast
+    projector's fused path reads cloud b // R of ``points_1`` directly (``views_per_cloud``), so a training step never
+    materialises it; anything else that asks for the key gets the reference's tensor."""
+
+    def __init__(self, base, repeats):
+        super().__init__(base)
+        self._repeats = int(repeats)
+        dict.__setitem__(self, "all_points", None)
+        self._pending = True
+
+    def points_replication(self):
+        """(clouds [B,N,3], R) while ``all_points`` has not been materialised (or overwritten), else None"""
+        return (dict.__getitem__(self, "points_1"), self._repeats) if self._pending else None
+
+    def __getitem__(self, k):
+        if k == "all_points" and self._pending:
+            self._pending = False
+            dict.__setitem__(self, k, tf_repeat_0(dict.__getitem__(self, "points_1"), self._repeats))
+        return dict.__getitem__(self, k)
+
+    def __setitem__(self, k, v):
+        if k == "all_points":
+            self._pending = False
+        dict.__setitem__(self, k, v)
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        self["all_points"]
+        return dict.items(self)
+
+    def values(self):
+        self["all_points"]
+        return dict.values(self)
+
+
 def get_smooth_sigma(cfg, global_step):
     """model_pc.py:35-40: linear anneal pc_relative_sigma -> pc_relative_sigma_end."""
     num_steps = cfg.max_number_of_steps
@@ -129,18 +168,25 @@ class ModelPointCloud(object):
     def get_dropout_keep_prob(self):
         return get_dropout_prob(self.cfg(), self._global_step)
 
-    def _fused_dropout_ok(self, all_points, all_rgb):
-        """The fused draw needs the fast projector's fused path, no colour channels and a losses set that
-        does not fetch the dense grids (cfg.pc_fused_dropout=False forces the explicit gather)."""
+    def _fused_path_ok(self, B, N, device, all_rgb):
+        """True when pointcloud_project_fast takes the fused front/back end for B instances of N points (the path
+        that implements the in-kernel dropout and replication): fast projector, no colour channels, and a loss set
+        that does not fetch the dense grids through the stage-level kernels."""
         cfg = self.cfg()
-        if not cfg.pc_fast or all_rgb is not None or not getattr(cfg, "pc_fused_dropout", True):
+        if not cfg.pc_fast or all_rgb is not None:
             return False
         if getattr(cfg, "drc_weight", 0.0):     # add_drc_loss fetches drc_probs (stage-level kernels, all N points)
             return False
         from .util.point_cloud import _flat_taps, _meta
-        taps = _flat_taps(cfg, self.gauss_kernel(), all_points.device)
+        taps = _flat_taps(cfg, self.gauss_kernel(), device)
         K = tuple(0 if t is None else int(t.numel()) for t in taps)
-        return ops.uses_fused_path(ops._capi.get_library(), all_points.shape[0], all_points.shape[1], _meta(cfg), K)
+        return ops.uses_fused_path(ops._capi.get_library(), B, N, _meta(cfg), K)
+
+    def _fused_dropout_ok(self, all_points, all_rgb, views_per_cloud=1):
+        """The fused draw needs the fused path (cfg.pc_fused_dropout=False forces the explicit gather)."""
+        if not getattr(self.cfg(), "pc_fused_dropout", True):
+            return False
+        return self._fused_path_ok(all_points.shape[0] * views_per_cloud, all_points.shape[1], all_points.device, all_rgb)
 
     @staticmethod
     def _rank_salt():
@@ -170,16 +216,15 @@ class ModelPointCloud(object):
         all_scaling_factors, all_focal_length, all_rgb."""
         cfg = self.cfg()
         C = cfg.pose_predict_num_candidates
-        all_points = self.replicate_for_multiview(outputs["points_1"])
+        # all_points = tf_repeat_0(tf_repeat_0(points_1, step_size), C) == tf_repeat_0(points_1, step_size * C): lazily
+        outputs = ReplicatedOutputs(outputs, cfg.step_size * (C if C > 1 else 1))
         all_focal_length = None
         if C > 1:
-            all_points = tf_repeat_0(all_points, C)
             if cfg.predict_translation:
                 outputs["predicted_translation"] = tf_repeat_0(outputs["predicted_translation"], C)
             if outputs.get("focal_length") is not None:
                 all_focal_length = tf_repeat_0(outputs["focal_length"], C)
         outputs["all_focal_length"] = all_focal_length
-        outputs["all_points"] = all_points
         if cfg.pc_learn_occupancy_scaling:
             s = self.replicate_for_multiview(outputs["scaling_factor"])
             if C > 1:
@@ -194,8 +239,16 @@ class ModelPointCloud(object):
 
     def compute_projection(self, inputs, outputs, is_training):   # model_pc.py:220-259
         cfg = self.cfg()
-        all_points = outputs["all_points"]
         all_rgb = outputs["all_rgb"]
+        # replication inside the kernels (views_per_cloud) whenever the fused path takes this shape: the [B,N,3]
+        # copies of the clouds and the reduction of their gradients are never built
+        views_per_cloud = None
+        rep = outputs.points_replication() if isinstance(outputs, ReplicatedOutputs) else None
+        if rep is not None and rep[1] > 1 and getattr(cfg, "pc_replicate_in_kernel", True) and \
+                self._fused_path_ok(rep[0].shape[0] * rep[1], rep[0].shape[1], rep[0].device, all_rgb):
+            all_points, views_per_cloud = rep
+        else:
+            all_points = outputs["all_points"]
         if cfg.predict_pose:
             camera_pose = outputs["poses"]
         elif cfg.pose_quaternion:
@@ -205,7 +258,7 @@ class ModelPointCloud(object):
         point_dropout = None
         if is_training and cfg.pc_point_dropout != 1:                      # model_pc.py:233-237
             keep_prob = self.get_dropout_keep_prob()
-            if self._fused_dropout_ok(all_points, all_rgb):
+            if self._fused_dropout_ok(all_points, all_rgb, views_per_cloud or 1):
                 # the draw happens inside the projector's depth sort (no [B,N',3] copy, no argsort)
                 if getattr(self, "_graph_replay", False):
                     point_dropout = self._advance_dropout_state()
@@ -217,12 +270,15 @@ class ModelPointCloud(object):
                     # the keep probability of the capture for ever
                     raise NotImplementedError("graph replay with point dropout needs the fused draw (fast projector's "
                                               "fused path, no colour channels, no drc loss)")
+                if views_per_cloud is not None:          # the explicit gather draws per INSTANCE: materialise the copies
+                    all_points, views_per_cloud = outputs["all_points"], None
                 all_points, all_rgb = pc_point_dropout(all_points, all_rgb, keep_prob)
         if cfg.pc_fast:
             predicted_translation = outputs["predicted_translation"] if cfg.predict_translation else None
             proj_out = pointcloud_project_fast(cfg, all_points, camera_pose, predicted_translation, all_rgb,
                                                self.gauss_kernel(), scaling_factor=outputs["all_scaling_factors"],
-                                               focal_length=outputs["all_focal_length"], point_dropout=point_dropout)
+                                               focal_length=outputs["all_focal_length"], point_dropout=point_dropout,
+                                               views_per_cloud=views_per_cloud)
             proj = proj_out["proj"]
             outputs["projs_rgb"] = proj_out["proj_rgb"]
             # TF1 only computes drc_probs ([Dz+1,B,D,D,1]) if a loss fetches it; here it is
@@ -231,7 +287,7 @@ class ModelPointCloud(object):
             outputs["drc_probs"] = proj_out["drc_probs"] if getattr(cfg, "drc_weight", 0.0) else None
             outputs["projs_depth"] = proj_out["proj_depth"]
         else:                                                                # model_pc.py:250-253
-            proj, _voxels = pointcloud_project(cfg, all_points, camera_pose, self.gauss_sigma())
+            proj, _voxels = pointcloud_project(cfg, outputs["all_points"], camera_pose, self.gauss_sigma())
             outputs["projs_rgb"] = None
             outputs["projs_depth"] = None
         outputs["projs"] = proj

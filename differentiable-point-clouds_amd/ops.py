@@ -15,10 +15,12 @@ from ._capi import DpcParams, DpcShape
 
 ProjMeta = collections.namedtuple(
     "ProjMeta", "Dz D camera_distance focal_length eps max_depth pose_quaternion collapse_mode dropout_keep dropout_seed "
-                "dropout_state l2_target l2_weight",
-    defaults=(0, 0, None, None, 0.0))
+                "dropout_state l2_target l2_weight views_per_cloud",
+    defaults=(0, 0, None, None, 0.0, 0))
 # dropout_state: int32[2] tensor {keep, seed} read by the kernels at run time (hipGraph replays)
 # l2_target / l2_weight: [B,D,D(,1)] image and factor of the fused L2 loss epilogue (ProjectFused's 4th output)
+# views_per_cloud: R > 1 = the point tensor holds B / R clouds, instance b projects cloud b // R (model_pc.py:270-279's
+#                  replication as an index inside the kernels); the point gradient comes back summed per cloud
 
 
 # ---------------------------------------------------------------------------
@@ -80,13 +82,13 @@ def _params(meta, l2_grad=None):
                      int(meta.dropout_keep), int(meta.dropout_seed) & 0xffffffff,
                      None if meta.dropout_state is None else meta.dropout_state.data_ptr(),
                      None if l2_grad is None else meta.l2_target.data_ptr(),
-                     None if l2_grad is None else l2_grad.data_ptr(), float(meta.l2_weight))
+                     None if l2_grad is None else l2_grad.data_ptr(), float(meta.l2_weight), int(meta.views_per_cloud))
 
 
 def _check_points(pc, pose, trans, scale, focal, meta):
     if pc.dim() != 3 or pc.shape[-1] != 3:
         raise ValueError("point_cloud must be [B,N,3], got %s" % (tuple(pc.shape),))
-    B = pc.shape[0]
+    B = pc.shape[0] * max(1, int(getattr(meta, "views_per_cloud", 0) or 1))
     if meta.pose_quaternion:
         if tuple(pose.shape) != (B, 4):
             raise ValueError("Can't create a quaternion from a tensor with shape %s. "
@@ -129,7 +131,7 @@ def _taps_of(taps):
 def uses_fused_path(lib, B, N, meta, K):
     """True when this shape takes the fused front/back end (depth-sorted points, per-plane LDS tiles): the
     only path that honours the fused point dropout."""
-    shape, params = _shape(B, N, meta, K), _params(meta)
+    shape, params = _shape(B, N, meta, K), _params(meta._replace(views_per_cloud=0))
     return bool(lib.dpc_saved_layout(ctypes.byref(shape), ctypes.byref(params)) & 2)
 
 
@@ -170,7 +172,7 @@ class _FusedPlan(object):
     def __init__(self, lib, B, N, meta, K):
         self.shape = _shape(B, N, meta, K)
         self.shape_ref = ctypes.byref(self.shape)
-        params = _params(meta._replace(l2_target=None, dropout_state=None))
+        params = _params(meta._replace(l2_target=None, dropout_state=None, views_per_cloud=0))
         self.layout = lib.dpc_saved_layout(self.shape_ref, ctypes.byref(params))
         lib.check(min(self.layout, 0), "dpc_saved_layout")
         self.ws_fwd = lib.dpc_workspace_bytes(self.shape_ref, 0)
@@ -233,10 +235,13 @@ class ProjectFused(torch.autograd.Function):
         lib = _lib_for(pc, pose, trans, scale, focal, tx, ty, tz)
         pc, pose, trans, scale, focal = _c(pc), _c(pose), _c(trans), _c(scale), _c(focal)
         (tx, ty, tz), K = _taps_of((tx, ty, tz))
-        B, N = pc.shape[0], pc.shape[1]
+        R = max(1, int(meta.views_per_cloud or 1))
+        B, N = pc.shape[0] * R, pc.shape[1]              # instances = clouds x views per cloud
         D = meta.D
         dev = pc.device
         plan = _fused_plan(lib, B, N, meta, K)
+        if R > 1 and not plan.layout & 2:
+            raise ValueError("views_per_cloud needs the fused path (power-of-two vox_size in [32,256], kernel size 5/11/21)")
         tgt = meta.l2_target
         if tgt is not None:
             if not plan.drc:
@@ -290,7 +295,8 @@ class ProjectFused(torch.autograd.Function):
         plan = ctx.plan
         meta = ctx.meta
         lib = _lib_for(pc)
-        B, N = pc.shape[0], pc.shape[1]
+        R = max(1, int(meta.views_per_cloud or 1))
+        B, N = pc.shape[0] * R, pc.shape[1]
         dev = pc.device
         params = _params(meta if meta.l2_target is None else meta._replace(l2_target=None))
         dproj, ddepth, dtr = _c(dproj), _c(ddepth), _c(dtr)
@@ -299,7 +305,7 @@ class ProjectFused(torch.autograd.Function):
         if dproj is None and ddepth is None:
             dproj = torch.zeros(B, meta.D, meta.D, 1, dtype=torch.float32, device=dev)
         new = lambda *s: _poison(torch.empty(*s, dtype=torch.float32, device=dev))
-        dpc = new(B, N, 3)
+        dpc = new(B // R, N, 3)               # per cloud: the kernels sum a cloud's R instances
         dpose = _poison(torch.empty_like(pose))
         dtrans = new(B, 3) if trans is not None else None
         dscale = new(B) if scale is not None else None

@@ -192,7 +192,7 @@ class ProjectionOutputs(dict):
 
 def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
                             all_rgb, kernel=None, scaling_factor=None, focal_length=None, *, point_dropout=None,
-                            l2_target=None):
+                            l2_target=None, views_per_cloud=None):
     """dpc/util/point_cloud.py:229-290.
 
     ``point_dropout=(num_keep, seed)`` (keyword-only, not in the reference signature) fuses
@@ -208,7 +208,12 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
     the collapse kernel: the result gains ``"proj_l2_grad"`` = weight * (proj - gt), the gradient of
     0.5 * weight * sum((proj - gt)^2) w.r.t. ``proj`` -- pass it to backward as the gradient of ``proj``
     (``torch.autograd.grad(out["proj"], inputs, out["proj_l2_grad"])``); gt is [B,D,D] or [B,D,D,1] at the
-    projection's own size."""
+    projection's own size.
+
+    ``views_per_cloud=R`` (keyword-only): ``point_cloud`` holds B / R clouds and instance b projects cloud b // R --
+    the reference's ``tf_repeat_0`` replication over views and pose candidates (model_pc.py:23-32,270-279) as an
+    index inside the kernels, so the [B,N,3] copies and their gradient reduction never exist; transform, translation,
+    scaling factor and focal length stay per instance ([B, ...]).  Fused path only, no colour channels."""
     meta = _meta(cfg)
     if point_dropout is not None:
         if all_rgb is not None:
@@ -223,6 +228,13 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
             meta = meta._replace(dropout_keep=int(point_dropout[0]), dropout_seed=int(point_dropout[1]) & 0xffffffff)
     if l2_target is not None:
         meta = meta._replace(l2_target=l2_target[0].detach(), l2_weight=float(l2_target[1]))
+    if views_per_cloud is not None and int(views_per_cloud) > 1:
+        if all_rgb is not None:
+            raise NotImplementedError("views_per_cloud with colour channels: replicate the cloud explicitly")
+        if transform.shape[0] != point_cloud.shape[0] * int(views_per_cloud):
+            raise ValueError("views_per_cloud=%d: %d clouds need %d poses, got %d" % (
+                int(views_per_cloud), point_cloud.shape[0], point_cloud.shape[0] * int(views_per_cloud), transform.shape[0]))
+        meta = meta._replace(views_per_cloud=int(views_per_cloud))
     tx, ty, tz = _flat_taps(cfg, kernel, point_cloud.device)
     proj, proj_depth, tr_pc, l2_grad = ops.ProjectFused.apply(point_cloud, transform, predicted_translation,
                                                               scaling_factor, focal_length, tx, ty, tz, meta)

@@ -81,6 +81,12 @@ typedef struct DpcParams {
   const float* l2_target;
   float* l2_grad;
   float l2_weight;
+  /* instance replication inside the kernels (tf_repeat_0 of dpc/models/model_pc.py:23-32 as used at :270-279: every
+   * predicted cloud is projected under step_size views x num_candidates poses): when > 1, `pc` holds B / views_per_cloud
+   * clouds [B / R, N, 3], instance b reads cloud b / R, and dpc_project_backward returns dpc as [B / R, N, 3] -- the sum
+   * over a cloud's R instances (the gradient of the replication) -- so that the [B,N,3] copies never exist.  0 or 1:
+   * one cloud per instance.  B must be a multiple of it; fused path only (DPC_E_MODE otherwise). */
+  int32_t views_per_cloud;
 } DpcParams;
 
 const char* dpc_version(void);
@@ -107,7 +113,7 @@ int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, 
 /* Which clip-gradient record dpc_project_forward leaves for the backward, for
  * this shape: bit 0 (value 1) = grid_raw, the dense pre-clip scatter [B,Dz,D,D]
  * (generic path: zero-fill + global float atomics); bit 1 (value 2) = clip_mask
- * [B,N,4] bytes, one bit per touched trilinear corner (fused path: points are
+ * 4*B*N bytes ([B,2,N,2]: view, corner plane, sorted slot, corner row), one bit per touched trilinear corner (fused path: points are
  * bucketed by depth cell and splatted into per-plane LDS tiles, the raw grid
  * never reaches HBM); bit 2 (value 4) = point_index, int32
  * [dpc_point_index_ints(shape)] = 5*B*N + B*(Dz+2) + B*8 (16-byte aligned): the points of

@@ -36,3 +36,57 @@ def test_emu_dropout_draw_read_back_through_the_c_abi(emu):
     pc = (0.25 * inp["pc"] / np.maximum(np.abs(inp["pc"]).max(), 1e-6)).astype(np.float32)    # |p| <= 0.44: inside the cube under any rotation
     got = parity_cases.fused_dropout_kept_mask_from_library("cpu", pc, inp["pose"], D, K, keep, seed)
     assert np.array_equal(got, dropout_ref.kept_mask(B, N, keep, seed))
+
+
+def test_emu_views_per_cloud_equals_explicit_replication(emu):
+    """pointcloud_project_fast(views_per_cloud=R) on [B/R,N,3] clouds == the same call on the tf_repeat_0 copies
+    (model_pc.py:23-32,270-279): images bit for bit, per-instance gradients alike, and the point gradient equal to the
+    sum over each cloud's R instances."""
+    import torch
+    import dpc_amd
+    C, R, N, D, K = 2, 3, 150, 32, 5
+    inp = synth.make_inputs(C * R, N, 321)
+    cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K)
+    kern = dpc_amd.smoothing_kernel(cfg, 0.9, device="cpu")
+    t = lambda a: torch.tensor(a, requires_grad=True)
+    clouds = t(inp["pc"][::R].copy())                       # C clouds
+    pose, scale = t(inp["pose"]), t(inp["scale"])
+    w = torch.tensor(np.random.default_rng(2).standard_normal((C * R, D, D, 1)).astype(np.float32))
+    a = dpc_amd.pointcloud_project_fast(cfg, clouds, pose, None, None, kern, scaling_factor=scale, views_per_cloud=R)
+    ga = torch.autograd.grad(a["proj"], [clouds, pose, scale], w)
+    clouds2, pose2, scale2 = t(inp["pc"][::R].copy()), t(inp["pose"]), t(inp["scale"])
+    rep = torch.repeat_interleave(clouds2, R, dim=0)
+    b = dpc_amd.pointcloud_project_fast(cfg, rep, pose2, None, None, kern, scaling_factor=scale2)
+    gb = torch.autograd.grad(b["proj"], [clouds2, pose2, scale2], w)
+    assert a["proj"].shape == (C * R, D, D, 1) and a["tr_pc"].shape == (C * R, N, 3)
+    assert float((a["proj"] - b["proj"]).abs().max()) == 0.0 and float((a["tr_pc"] - b["tr_pc"]).abs().max()) == 0.0
+    assert ga[0].shape == (C, N, 3)
+    for x, y in zip(ga, gb):
+        assert float((x - y).abs().max()) <= 1e-6 * max(1.0, float(y.abs().max()))
+    with pytest.raises(ValueError):
+        dpc_amd.pointcloud_project_fast(cfg, clouds, pose[:4], None, None, kern, views_per_cloud=R)
+
+
+def test_emu_model_replicates_inside_the_kernels(emu):
+    """ModelPointCloud.replicate_outputs leaves `all_points` unbuilt; compute_projection hands points_1 and the
+    replication factor to the projector; the result equals the explicit path (pc_replicate_in_kernel=False)."""
+    import torch
+    import dpc_amd
+    res = {}
+    for in_kernel in (True, False):
+        cfg = dpc_amd.default_config(vox_size=32, pc_gauss_kernel_size=5, pc_num_points=120, predict_pose=True,
+                                     pose_predict_num_candidates=2, step_size=2, batch_size=2, pc_point_dropout=1.0,
+                                     pc_replicate_in_kernel=in_kernel)
+        m = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device="cpu")
+        inp = synth.make_inputs(2, 120, 5)
+        pts = torch.tensor(inp["pc"], requires_grad=True)
+        poses = torch.tensor(synth.make_inputs(8, 4, 6)["pose"])
+        outputs = m.replicate_outputs({"points_1": pts, "poses": poses, "scaling_factor": torch.full((2, 1), 0.8)})
+        assert outputs.points_replication() is not None and outputs.points_replication()[1] == 4
+        outputs = m.compute_projection({}, outputs, is_training=True)
+        assert (outputs.points_replication() is not None) == in_kernel       # the copies were only built on the explicit path
+        g = torch.autograd.grad(outputs["projs"].sum(), [pts])[0]
+        res[in_kernel] = (outputs["projs"].detach(), g)
+        assert outputs["all_points"].shape == (8, 120, 3)                    # still there for whoever asks
+    assert float((res[True][0] - res[False][0]).abs().max()) == 0.0
+    assert float((res[True][1] - res[False][1]).abs().max()) <= 1e-6 * float(res[False][1].abs().max())
