@@ -171,6 +171,21 @@ int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, 
     DPC_LAUNCH("copy2", (k_copy<2>), grid, block, 0, st, src, dst, n);
   else if (width == 1)
     DPC_LAUNCH("copy1", (k_copy<1>), grid, block, 0, st, src, dst, n);
+  else if (width == 44 || width == 48 || width == 144 || width == 148) {
+    // ceiling variants: float4, 4 or 8 loads in flight per lane; 1xx = nontemporal loads and stores.  n must be a
+    // multiple of the grid's footprint (4 * U * threads floats) -- bench.py's buffers are.
+    const int U = (width % 100) - 40;
+    const size_t per = (size_t)4 * U * DPC_BLOCK;
+    if (n % per != 0) return DPC_E_SHAPE;
+    size_t blocks = n / per;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    while ((n / per) % blocks != 0) --blocks;
+    const dim3 g((unsigned)blocks, 1, 1);
+    if (width == 44) DPC_LAUNCH("copy4x4", (k_copy_unrolled<4, false>), g, block, 0, st, src, dst, n);
+    else if (width == 48) DPC_LAUNCH("copy4x8", (k_copy_unrolled<8, false>), g, block, 0, st, src, dst, n);
+    else if (width == 144) DPC_LAUNCH("copy4x4nt", (k_copy_unrolled<4, true>), g, block, 0, st, src, dst, n);
+    else DPC_LAUNCH("copy4x8nt", (k_copy_unrolled<8, true>), g, block, 0, st, src, dst, n);
+  }
   else
     return DPC_E_MODE;
   hipError_t e = hipGetLastError();

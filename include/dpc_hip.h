@@ -107,7 +107,10 @@ int dpc_profile_get(int i, const char** label, float* ms);
 
 /* Diagnostic: grid-stride copy of n floats (n % 4 == 0) with `width` (1|2|4)
  * floats per lane -- a kernel with exactly known HBM traffic (4n read, 4n
- * written) used to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters. */
+ * written) used to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters.
+ * width 44 / 48: float4 with 4 / 8 loads in flight per lane, 144 / 148: the same with the
+ * nontemporal policy (n a multiple of 4096 * that count) -- the variants bench.py takes its
+ * on-box copy ceiling from. */
 int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, int width);
 
 /* Which clip-gradient record dpc_project_forward leaves for the backward, for

@@ -16,8 +16,11 @@ if old:
         os.remove(f)
 names = {"00_env.log": "env.log", "01_pytest_gpu.log": "pytest_gpu.log", "02_smoke.log": "smoke.log",
          "08_summary.txt": "rocprof_summary.txt"}
+names["10_sq_counters_cfg2.txt"] = "sq_counters_cfg2.txt"
+names["10_sq_counters_cfg3p.txt"] = "sq_counters_cfg3p.txt"
 for a, b in names.items():
-    shutil.copy(os.path.join(src, a), os.path.join(dst, "%s_%s" % (pre, b)))
+    if os.path.exists(os.path.join(src, a)):        # (a session run with SKIP_TESTS / SKIP_SQ leaves some out)
+        shutil.copy(os.path.join(src, a), os.path.join(dst, "%s_%s" % (pre, b)))
 for f in glob.glob(os.path.join(src, "0[345]_bench_*.json")):
     shutil.copy(f, os.path.join(dst, "%s_%s" % (pre, os.path.basename(f)[3:])))
 for f in glob.glob(os.path.join(src, "09_train_step_example_*.json")):
