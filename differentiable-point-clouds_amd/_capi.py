@@ -38,7 +38,10 @@ class DpcParams(ctypes.Structure):
                 ("pose_is_quaternion", ctypes.c_int32), ("collapse_mode", ctypes.c_int32),
                 ("flags", ctypes.c_int32), ("dropout_keep", ctypes.c_int32), ("dropout_seed", ctypes.c_uint32),
                 ("dropout_state", ctypes.c_void_p), ("l2_target", ctypes.c_void_p), ("l2_grad", ctypes.c_void_p),
-                ("l2_weight", ctypes.c_float), ("views_per_cloud", ctypes.c_int32)]
+                ("l2_weight", ctypes.c_float), ("views_per_cloud", ctypes.c_int32),
+                ("sil_gt", ctypes.c_void_p), ("sil_err_parts", ctypes.c_void_p), ("sil_weight", ctypes.c_void_p),
+                ("sil_dloss", ctypes.c_void_p), ("sil_proj", ctypes.c_void_p), ("sil_C", ctypes.c_int32),
+                ("sil_S", ctypes.c_int32)]
 
 
 _P = ctypes.c_void_p
@@ -74,6 +77,8 @@ SIGNATURES = {
     "dpc_silhouette_loss_bwd": (ctypes.c_int, [_P] + [ctypes.c_int] * 4 + [_P] * 5),
     "dpc_student_loss": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, ctypes.c_float, _P, _P]),
     "dpc_point_index_ints": (ctypes.c_size_t, [_SP]),
+    "dpc_sil_parts_per_view": (ctypes.c_size_t, [_SP]),
+    "dpc_silhouette_select": (ctypes.c_int, [_P] + [ctypes.c_int] * 3 + [_P] * 6),
     "dpc_nn_distance": (ctypes.c_int, [_P] + [ctypes.c_int] * 3 + [_P] * 5),
     "dpc_gauss_voxelize_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "dpc_gauss_voxelize_fwd": (ctypes.c_int, [_P] + [ctypes.c_int] * 3 + [_P, ctypes.c_float, ctypes.c_int] + [_P] * 4),

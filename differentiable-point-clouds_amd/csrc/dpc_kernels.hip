@@ -155,6 +155,23 @@ int dpc_saved_layout(const DpcShape* shape, const DpcParams* params) {
   return 6 | (save_xy_mode(*shape, params->collapse_mode == DPC_COLLAPSE_DRC) ? 8 : 0);
 }
 
+size_t dpc_sil_parts_per_view(const DpcShape* shape) {
+  if (check_shape(shape, true) != DPC_OK || !splat_plan(*shape).ok) return 0;
+  return ((size_t)shape->D * shape->D / pick_cx(shape->D)) % DPC_BLOCK == 0 ? (size_t)zbwd_blocks(*shape) : 0;
+}
+
+int dpc_silhouette_select(dpc_stream_t stream, int B, int C, int nparts, const float* err_parts, const float* valid,
+                          float* inst_err, int32_t* winners, float* weight, float* loss) {
+  if (B <= 0 || C <= 0 || B % C != 0 || nparts <= 0) return DPC_E_SHAPE;
+  if (!err_parts || !inst_err || !weight || !loss) return DPC_E_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  DPC_LAUNCH("sil_sum_parts", (k_sil_sum_parts), dim3((B + DPC_BLOCK - 1) / DPC_BLOCK, 1, 1), dim3(DPC_BLOCK, 1, 1), 0, st,
+             err_parts, inst_err, B, nparts);
+  DPC_LAUNCH("sil_select", (k_sil_select), dim3(1, 1, 1), dim3(DPC_BLOCK, 1, 1), 0, st, (const float*)inst_err, valid,
+             (int*)winners, weight, loss, B / C, C);
+  return last_error();
+}
+
 size_t dpc_point_index_ints(const DpcShape* shape) {
   if (check_shape(shape, true) != DPC_OK || !splat_plan(*shape).ok) return 0;
   return point_index_ints(*shape);
@@ -374,6 +391,10 @@ int dpc_project_forward(dpc_stream_t stream, const DpcShape* shape, const DpcPar
   if (drc && !ray_sums) return DPC_E_NULL;
   if (P.l2_target && !drc) return DPC_E_MODE;   // the L2 epilogue lives in the DRC collapse kernel
   if (P.l2_target && !P.l2_grad) return DPC_E_NULL;
+  if (P.sil_gt && P.sil_err_parts) {        // fused candidate-loss epilogue: DRC collapse of the fused path, whole work-groups
+    if (!drc || dpc_sil_parts_per_view(shape) == 0 || !z_fixed(S.Kz)) return DPC_E_MODE;
+    if (P.sil_C <= 0 || S.B % P.sil_C != 0 || P.sil_S < S.D) return DPC_E_SHAPE;
+  }
   const SplatPlan plan = splat_plan(S);
   if (P.views_per_cloud > 1 && (!plan.ok || S.B % P.views_per_cloud != 0)) return DPC_E_MODE;   // replication lives in the fused path's kernels
   if (plan.ok ? (!clip_mask || !point_index) : !grid_raw) return DPC_E_NULL;
@@ -470,7 +491,12 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   if (!P.pose_is_quaternion && trans) return DPC_E_MODE;
   const bool drc = P.collapse_mode == DPC_COLLAPSE_DRC;
   if (!drc && P.collapse_mode != DPC_COLLAPSE_MAX) return DPC_E_MODE;
-  if (!dproj && !(drc && dproj_depth)) return DPC_E_NULL;
+  if (P.sil_weight) {
+    if (!drc || !splat_plan(S).ok || !z_fixed(S.Kz)) return DPC_E_MODE;
+    if (!P.sil_gt || !P.sil_dloss || !P.sil_proj) return DPC_E_NULL;
+    if (P.sil_C <= 0 || S.B % P.sil_C != 0 || P.sil_S < S.D) return DPC_E_SHAPE;
+  }
+  if (!dproj && !(drc && dproj_depth) && !P.sil_weight) return DPC_E_NULL;
   if (scale && !dscale) return DPC_E_NULL;
   const SplatPlan plan = splat_plan(S);
   if (P.views_per_cloud > 1 && (!plan.ok || S.B % P.views_per_cloud != 0)) return DPC_E_MODE;

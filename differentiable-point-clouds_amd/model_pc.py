@@ -275,10 +275,14 @@ class ModelPointCloud(object):
                 all_points, all_rgb = pc_point_dropout(all_points, all_rgb, keep_prob)
         if cfg.pc_fast:
             predicted_translation = outputs["predicted_translation"] if cfg.predict_translation else None
+            sil = self._fused_proj_loss_target(inputs, all_points, views_per_cloud or 1, all_rgb)
             proj_out = pointcloud_project_fast(cfg, all_points, camera_pose, predicted_translation, all_rgb,
                                                self.gauss_kernel(), scaling_factor=outputs["all_scaling_factors"],
                                                focal_length=outputs["all_focal_length"], point_dropout=point_dropout,
-                                               views_per_cloud=views_per_cloud)
+                                               views_per_cloud=views_per_cloud, silhouette_target=sil)
+            if sil is not None:      # add_proj_loss picks these up instead of launching the loss epilogue on `projs`
+                outputs["_fused_proj_loss"] = (proj_out["proj_loss"], proj_out["winning_pose_candidates"], sil[0])
+                self._last_inst_err = proj_out["proj_inst_err"]
             proj = proj_out["proj"]
             outputs["projs_rgb"] = proj_out["proj_rgb"]
             # TF1 only computes drc_probs ([Dz+1,B,D,D,1]) if a loss fetches it; here it is
@@ -294,6 +298,27 @@ class ModelPointCloud(object):
         batch_size = outputs["points_1"].shape[0]
         outputs["projs_1"] = proj[0:batch_size]
         return outputs
+
+    def _fused_proj_loss_target(self, inputs, all_points, views_per_cloud, all_rgb):
+        """(masks, num_candidates, valid) when add_proj_loss's silhouette term can be evaluated inside the projector's
+        collapse kernels (cfg.pc_fused_proj_loss, default on): the loss is switched on, the masks are at hand and go
+        in unfiltered (pc_gauss_filter_gt blurs them with a host-side sigma first), the fused path takes the shape."""
+        cfg = self.cfg()
+        if not getattr(cfg, "pc_fused_proj_loss", True) or not cfg.proj_weight or cfg.ptn_max_projection:
+            return None
+        masks = inputs.get("masks") if hasattr(inputs, "get") else None
+        if masks is None or cfg.pc_gauss_filter_gt or masks.dim() != 4 or masks.shape[1] < cfg.vox_size:
+            return None
+        if masks.shape[1] > cfg.vox_size and cfg.bicubic_gt_downsampling:
+            return None
+        B = all_points.shape[0] * views_per_cloud
+        C = cfg.pose_predict_num_candidates
+        if B % C != 0 or masks.shape[0] != B // C:
+            return None
+        if not self._fused_path_ok(B, all_points.shape[1], all_points.device, all_rgb):
+            return None
+        valid = inputs["valid_samples"] if (cfg.variable_num_views and C > 1) else None
+        return masks, C, valid
 
     def proj_loss_pose_candidates(self, gt, pred, inputs):     # model_pc.py:308-337
         """gt [B*V,S,S,1] (S >= pred size; resized inside the kernel), pred [B*V*C,D,D,1]
@@ -345,7 +370,15 @@ class ModelPointCloud(object):
                 gt = smoothed
         total_loss = 0
         # otherwise the bilinear GT resize (model_pc.py:392-397) happens inside the loss kernel
-        if cfg.pose_predict_num_candidates > 1:
+        fused = outputs.get("_fused_proj_loss")
+        if fused is not None and fused[2] is inputs["masks"] and not cfg.pc_gauss_filter_gt:
+            # compute_projection already evaluated this loss inside the collapse kernels (same masks, same candidates)
+            proj_loss, min_loss = fused[0], fused[1]
+            if cfg.pose_predict_num_candidates > 1:
+                outputs["winning_pose_candidates"] = min_loss
+                if cfg.pose_predictor_student:
+                    total_loss = total_loss + self.add_student_loss(inputs, outputs, min_loss, add_summary)
+        elif cfg.pose_predict_num_candidates > 1:
             proj_loss, min_loss = self.proj_loss_pose_candidates(gt, pred, inputs)
             outputs["winning_pose_candidates"] = min_loss
             if cfg.pose_predictor_student:

@@ -15,12 +15,15 @@ from ._capi import DpcParams, DpcShape
 
 ProjMeta = collections.namedtuple(
     "ProjMeta", "Dz D camera_distance focal_length eps max_depth pose_quaternion collapse_mode dropout_keep dropout_seed "
-                "dropout_state l2_target l2_weight views_per_cloud",
-    defaults=(0, 0, None, None, 0.0, 0))
+                "dropout_state l2_target l2_weight views_per_cloud sil_gt sil_C sil_valid",
+    defaults=(0, 0, None, None, 0.0, 0, None, 1, None))
 # dropout_state: int32[2] tensor {keep, seed} read by the kernels at run time (hipGraph replays)
 # l2_target / l2_weight: [B,D,D(,1)] image and factor of the fused L2 loss epilogue (ProjectFused's 4th output)
 # views_per_cloud: R > 1 = the point tensor holds B / R clouds, instance b projects cloud b // R (model_pc.py:270-279's
 #                  replication as an index inside the kernels); the point gradient comes back summed per cloud
+# sil_gt / sil_C / sil_valid: masks [B/C,S,S(,1)], candidates per (model, view) group, per-group weights | None: the
+#                  candidate silhouette loss (model_pc.py:308-337, 383-423) evaluated inside the z kernels
+#                  (ProjectFused's 5th..7th outputs: loss, winners, per-instance errors)
 
 
 # ---------------------------------------------------------------------------
@@ -76,7 +79,16 @@ def _shape(B, N, meta, K=(0, 0, 0)):
     return DpcShape(int(B), int(N), int(meta.Dz), int(meta.D), int(K[0]), int(K[1]), int(K[2]))
 
 
-def _params(meta, l2_grad=None):
+def _params(meta, l2_grad=None, sil=None):
+    """sil = (gt_ptr, err_parts_ptr, weight_ptr, dloss_ptr, proj_ptr, C, S) of the fused candidate-loss epilogue"""
+    if sil is not None:
+        return DpcParams(float(meta.camera_distance), float(meta.focal_length), float(meta.eps),
+                         float(meta.max_depth), 1 if meta.pose_quaternion else 0, int(meta.collapse_mode), 0,
+                         int(meta.dropout_keep), int(meta.dropout_seed) & 0xffffffff,
+                         None if meta.dropout_state is None else meta.dropout_state.data_ptr(),
+                         None if l2_grad is None else meta.l2_target.data_ptr(),
+                         None if l2_grad is None else l2_grad.data_ptr(), float(meta.l2_weight), int(meta.views_per_cloud),
+                         *sil)
     return DpcParams(float(meta.camera_distance), float(meta.focal_length), float(meta.eps),
                      float(meta.max_depth), 1 if meta.pose_quaternion else 0, int(meta.collapse_mode), 0,
                      int(meta.dropout_keep), int(meta.dropout_seed) & 0xffffffff,
@@ -131,7 +143,7 @@ def _taps_of(taps):
 def uses_fused_path(lib, B, N, meta, K):
     """True when this shape takes the fused front/back end (depth-sorted points, per-plane LDS tiles): the
     only path that honours the fused point dropout."""
-    shape, params = _shape(B, N, meta, K), _params(meta._replace(views_per_cloud=0))
+    shape, params = _shape(B, N, meta, K), _params(meta._replace(views_per_cloud=0, sil_gt=None))
     return bool(lib.dpc_saved_layout(ctypes.byref(shape), ctypes.byref(params)) & 2)
 
 
@@ -167,12 +179,12 @@ class _FusedPlan(object):
     ONE arena allocation, and the workspace sizes.  ProjectFused runs every training step; asking the library
     three questions and building ~10 tensors per call was most of its host time."""
     __slots__ = ("shape", "shape_ref", "layout", "ws_fwd", "ws_bwd", "drc", "off_raw", "off_cmask", "off_pindex",
-                 "off_blur", "off_sums", "arena_bytes", "n_out")
+                 "off_blur", "off_sums", "arena_bytes", "n_out", "sil_parts")
 
     def __init__(self, lib, B, N, meta, K):
         self.shape = _shape(B, N, meta, K)
         self.shape_ref = ctypes.byref(self.shape)
-        params = _params(meta._replace(l2_target=None, dropout_state=None, views_per_cloud=0))
+        params = _params(meta._replace(l2_target=None, dropout_state=None, views_per_cloud=0, sil_gt=None))
         self.layout = lib.dpc_saved_layout(self.shape_ref, ctypes.byref(params))
         lib.check(min(self.layout, 0), "dpc_saved_layout")
         self.ws_fwd = lib.dpc_workspace_bytes(self.shape_ref, 0)
@@ -192,6 +204,7 @@ class _FusedPlan(object):
             self.off_sums, off = off, off + _a256(16 * B * meta.D * meta.D)      # [B,D,D,2] float64
         self.arena_bytes = off + 256
         self.n_out = 2 if self.drc else 1                     # proj (+ proj_depth)
+        self.sil_parts = int(lib.dpc_sil_parts_per_view(self.shape_ref)) if self.drc else 0
 
 
 _PLANS = {}
@@ -257,6 +270,22 @@ class ProjectFused(torch.autograd.Function):
         if (0 < meta.dropout_keep < N or st is not None) and not plan.layout & 2:
             raise ValueError("fused point dropout needs the fused path (power-of-two vox_size in [32,256], kernel size "
                              "5/11/21, vox_size_z <= 256); use pc_point_dropout for this shape")
+        sgt = meta.sil_gt
+        sil = None
+        if sgt is not None:
+            C = int(meta.sil_C)
+            if not plan.sil_parts:
+                raise ValueError("the fused candidate-loss epilogue needs the fused path with the DRC collapse")
+            if C <= 0 or B % C != 0:
+                raise ValueError("B=%d instances do not split into groups of %d pose candidates" % (B, C))
+            if sgt.dim() not in (3, 4) or sgt.shape[0] != B // C or sgt.shape[1] != sgt.shape[2] or sgt.shape[1] < D \
+                    or not sgt.is_contiguous() or sgt.dtype != torch.float32 or sgt.device != dev:
+                raise ValueError("silhouette masks must be contiguous float32 [%d,S,S(,1)] with S >= %d on the points' device, got %s"
+                                 % (B // C, D, tuple(sgt.shape)))
+            sval = meta.sil_valid
+            if sval is not None and (sval.numel() != B // C or sval.dtype != torch.float32 or not sval.is_contiguous()
+                                     or sval.device != dev):
+                raise ValueError("valid_samples must be %d contiguous float32 values on the points' device" % (B // C))
         n_img = plan.n_out + (1 if tgt is not None else 0)
         imgs = torch.empty(n_img, B, D, D, 1, dtype=torch.float32, device=dev)      # proj | proj_depth | l2_grad
         tr_pc = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
@@ -271,7 +300,10 @@ class ProjectFused(torch.autograd.Function):
         proj = views[0]
         depth = views[1] if plan.drc else None
         l2_grad = views[plan.n_out] if tgt is not None else None
-        params = _params(meta, l2_grad)
+        if sgt is not None:
+            err_parts = torch.empty(B, plan.sil_parts, dtype=torch.float32, device=dev)
+            sil = (sgt.data_ptr(), err_parts.data_ptr(), None, None, None, int(meta.sil_C), int(sgt.shape[1]))
+        params = _params(meta, l2_grad, sil)
         base = _a256(arena.data_ptr())
         rc = lib.dpc_project_forward(_stream_int(lib, dev), plan.shape_ref, ctypes.byref(params),
                                      pc.data_ptr(), pose.data_ptr(), _ptr(trans), _ptr(scale), _ptr(focal),
@@ -280,29 +312,51 @@ class ProjectFused(torch.autograd.Function):
                                      _at(base, plan.off_sums), proj.data_ptr(), _ptr(depth),
                                      _a256(work.data_ptr()), plan.ws_fwd)
         lib.check(rc, "dpc_project_forward")
+        sil_loss = sil_win = sil_err = sil_w = None
+        if sgt is not None:
+            # per-instance errors from the collapse kernel's partials, arg-min over the candidates, weights, loss
+            C = int(meta.sil_C)
+            sil_err = torch.empty(B, dtype=torch.float32, device=dev)
+            sil_w = torch.empty(B, dtype=torch.float32, device=dev)
+            win32 = torch.empty(B // C, dtype=torch.int32, device=dev)
+            sil_loss = torch.empty((), dtype=torch.float32, device=dev)
+            rc = lib.dpc_silhouette_select(_stream_int(lib, dev), B, C, plan.sil_parts, err_parts.data_ptr(),
+                                           _ptr(meta.sil_valid), sil_err.data_ptr(), win32.data_ptr(), sil_w.data_ptr(),
+                                           sil_loss.data_ptr())
+            lib.check(rc, "dpc_silhouette_select")
+            sil_win = win32.to(torch.int64)
         ctx.meta, ctx.K, ctx.plan = meta, K, plan
         ctx.set_materialize_grads(False)     # unused outputs (depth, tr_pc) arrive as None, not as zero fills
         ctx.scale_shape = None if scale is None else tuple(scale.shape)
         ctx.focal_shape = None if focal is None else tuple(focal.shape)
-        ctx.save_for_backward(pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, arena)
+        ctx.save_for_backward(pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, arena, sgt, sil_w,
+                              proj if sgt is not None else None)
         if l2_grad is not None:
             ctx.mark_non_differentiable(l2_grad)
-        return proj, depth, tr_pc, l2_grad
+        if sgt is not None:
+            ctx.mark_non_differentiable(sil_win, sil_err)
+        return proj, depth, tr_pc, l2_grad, sil_loss, sil_win, sil_err
 
     @staticmethod
-    def backward(ctx, dproj, ddepth, dtr, _dl2=None):
-        pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, arena = ctx.saved_tensors
+    def backward(ctx, dproj, ddepth, dtr, _dl2=None, dsil=None, _dwin=None, _derr=None):
+        pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, arena, sgt, sil_w, sil_proj = ctx.saved_tensors
         plan = ctx.plan
         meta = ctx.meta
         lib = _lib_for(pc)
         R = max(1, int(meta.views_per_cloud or 1))
         B, N = pc.shape[0] * R, pc.shape[1]
         dev = pc.device
-        params = _params(meta if meta.l2_target is None else meta._replace(l2_target=None))
+        sil = None
+        if sgt is not None and dsil is not None:
+            # the candidate loss's gradient w.r.t. proj is formed inside the collapse VJP from (proj, masks, weights)
+            dsil = _c(dsil.to(torch.float32))
+            sil = (sgt.data_ptr(), None, sil_w.data_ptr(), dsil.data_ptr(), sil_proj.data_ptr(), int(meta.sil_C),
+                   int(sgt.shape[1]))
+        params = _params(meta if meta.l2_target is None else meta._replace(l2_target=None), None, sil)
         dproj, ddepth, dtr = _c(dproj), _c(ddepth), _c(dtr)
         if not plan.drc:
             ddepth = None
-        if dproj is None and ddepth is None:
+        if dproj is None and ddepth is None and sil is None:
             dproj = torch.zeros(B, meta.D, meta.D, 1, dtype=torch.float32, device=dev)
         new = lambda *s: _poison(torch.empty(*s, dtype=torch.float32, device=dev))
         dpc = new(B // R, N, 3)               # per cloud: the kernels sum a cloud's R instances

@@ -192,7 +192,7 @@ class ProjectionOutputs(dict):
 
 def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
                             all_rgb, kernel=None, scaling_factor=None, focal_length=None, *, point_dropout=None,
-                            l2_target=None, views_per_cloud=None):
+                            l2_target=None, views_per_cloud=None, silhouette_target=None):
     """dpc/util/point_cloud.py:229-290.
 
     ``point_dropout=(num_keep, seed)`` (keyword-only, not in the reference signature) fuses
@@ -213,7 +213,14 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
     ``views_per_cloud=R`` (keyword-only): ``point_cloud`` holds B / R clouds and instance b projects cloud b // R --
     the reference's ``tf_repeat_0`` replication over views and pose candidates (model_pc.py:23-32,270-279) as an
     index inside the kernels, so the [B,N,3] copies and their gradient reduction never exist; transform, translation,
-    scaling factor and focal length stay per instance ([B, ...]).  Fused path only, no colour channels."""
+    scaling factor and focal length stay per instance ([B, ...]).  Fused path only, no colour channels.
+
+    ``silhouette_target=(masks, num_candidates, valid_samples | None)`` (keyword-only): the silhouette loss of
+    model_pc.py:383-423 with the min over pose candidates of :308-337 evaluated inside the collapse kernels -- masks
+    [B / C, S, S, 1] (S >= vox_size, resized bilinearly the TF1 way on the fly).  The result gains ``"proj_loss"`` (the
+    scalar sum_g valid_g^2 min_c |gt_g - proj_gc|^2 / (2 B/C), differentiable: its gradient w.r.t. ``proj`` is formed
+    inside the backward kernels, no dproj image exists), ``"winning_pose_candidates"`` [B / C] and ``"proj_inst_err"`` [B].
+    Fused path, DRC collapse."""
     meta = _meta(cfg)
     if point_dropout is not None:
         if all_rgb is not None:
@@ -235,9 +242,15 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
             raise ValueError("views_per_cloud=%d: %d clouds need %d poses, got %d" % (
                 int(views_per_cloud), point_cloud.shape[0], point_cloud.shape[0] * int(views_per_cloud), transform.shape[0]))
         meta = meta._replace(views_per_cloud=int(views_per_cloud))
+    if silhouette_target is not None:
+        sgt, sC, sval = silhouette_target
+        sgt = sgt.detach().to(device=point_cloud.device, dtype=torch.float32).contiguous()
+        if sval is not None:
+            sval = sval.detach().to(device=point_cloud.device, dtype=torch.float32).reshape(-1).contiguous()
+        meta = meta._replace(sil_gt=sgt, sil_C=int(sC), sil_valid=sval)
     tx, ty, tz = _flat_taps(cfg, kernel, point_cloud.device)
-    proj, proj_depth, tr_pc, l2_grad = ops.ProjectFused.apply(point_cloud, transform, predicted_translation,
-                                                              scaling_factor, focal_length, tx, ty, tz, meta)
+    proj, proj_depth, tr_pc, l2_grad, sil_loss, sil_win, sil_err = ops.ProjectFused.apply(
+        point_cloud, transform, predicted_translation, scaling_factor, focal_length, tx, ty, tz, meta)
     state = {}
 
     def make_voxels():
@@ -283,6 +296,8 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
     eager = {"proj": proj, "tr_pc": tr_pc, "voxels_rgb": voxels_rgb, "proj_rgb": proj_rgb, "proj_depth": proj_depth}
     if l2_target is not None:
         eager["proj_l2_grad"] = l2_grad
+    if silhouette_target is not None:
+        eager["proj_loss"], eager["winning_pose_candidates"], eager["proj_inst_err"] = sil_loss, sil_win, sil_err
     out = ProjectionOutputs(eager, make_voxels, make_probs)
     return out
 

@@ -87,6 +87,20 @@ typedef struct DpcParams {
    * over a cloud's R instances (the gradient of the replication) -- so that the [B,N,3] copies never exist.  0 or 1:
    * one cloud per instance.  B must be a multiple of it; fused path only (DPC_E_MODE otherwise). */
   int32_t views_per_cloud;
+  /* silhouette-loss epilogue with pose candidates inside the z kernels (dpc/models/model_pc.py:308-337 and :383-423):
+   * forward: when sil_gt (device, [B / sil_C, sil_S, sil_S] masks, sil_S >= D; resized bilinearly the TF1 way on the
+   * fly) and sil_err_parts (device, [B, dpc_sil_parts_per_view(shape)]) are set, the collapse kernel also leaves the
+   * per-work-group partial sums of (gt - proj)^2 of every instance -- dpc_silhouette_select turns them into the
+   * per-instance errors, the winning candidate of every (model, view) group, the weights and the loss, without reading
+   * proj again.  backward: when sil_weight ([B], from dpc_silhouette_select), sil_dloss ([1], d L / d loss) and sil_proj
+   * ([B,D,D], the forward's proj) are set, the collapse VJP adds sil_dloss * w_b^2 / (B / sil_C) * (proj - gt) to
+   * dproj (which may then be null) itself: no dproj image is formed.  DRC collapse, fused path only. */
+  const float* sil_gt;
+  float* sil_err_parts;
+  const float* sil_weight;
+  const float* sil_dloss;
+  const float* sil_proj;
+  int32_t sil_C, sil_S;
 } DpcParams;
 
 const char* dpc_version(void);
@@ -126,6 +140,14 @@ int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, 
  * bit 3 (value 8, informational) = grid_blur holds the xy-blurred grid rather
  * than G2.  Buffers that are not used may be null.  <0 on error. */
 int dpc_saved_layout(const DpcShape* shape, const DpcParams* params);
+/* Partial sums per instance that the fused silhouette-loss epilogue leaves in DpcParams.sil_err_parts
+ * (= the collapse kernel's work-groups per view), 0 when the shape cannot use it. */
+size_t dpc_sil_parts_per_view(const DpcShape* shape);
+/* The loss side of that epilogue: inst_err[b] = fixed-order sum of the partials; then, as dpc_silhouette_loss_fwd:
+ * winners [B/C] (first minimum), weight [B] = [c == winner] * valid (valid nullable; ignored for C == 1),
+ * loss = sum_g valid_g^2 err[g, win] / (2 B/C). */
+int dpc_silhouette_select(dpc_stream_t stream, int B, int C, int nparts, const float* err_parts, const float* valid,
+                          float* inst_err, int32_t* winners, float* weight, float* loss);
 /* Number of int32 elements of the point_index buffer (0 when the shape does not
  * use it). */
 size_t dpc_point_index_ints(const DpcShape* shape);

@@ -692,3 +692,37 @@ def assert_dropout_statistics(st, sigmas=5.0, zmax=6.0):
         chi, df = st["chi_" + tag], st["df_" + tag]
         assert abs(chi - df) < sigmas * np.sqrt(2.0 * df), (tag, st)
         assert st["zmax_" + tag] < zmax, (tag, st)
+
+
+def fused_candidate_loss_equals_the_image_epilogue(dev, B=8, C=4, N=300, D=32, K=5, S=48, with_valid=True, rep=1):
+    """pointcloud_project_fast(silhouette_target=...) -- per-instance errors from k_zfwd's partials, arg-min / weights /
+    loss in dpc_silhouette_select, the loss gradient formed inside k_zbwd -- against ops.SilhouetteLoss run on the
+    projection image (dpc_silhouette_loss_fwd/bwd, itself pinned by the reference goldens caller_loss*.npz): loss,
+    winners, per-instance errors and every input gradient."""
+    rng = np.random.default_rng(100 + B + D)
+    inp = synth.make_inputs(B, N, 8181)
+    cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K)
+    kern = dpc_amd.smoothing_kernel(cfg, 0.9, device=dev)
+    G = B // C
+    gt = torch.tensor((rng.uniform(size=(G, S, S, 1)) > 0.6).astype(np.float32), device=dev)
+    valid = torch.tensor(rng.uniform(0.5, 1.0, G).astype(np.float32), device=dev) if with_valid else None
+    res = {}
+    for fused in (True, False):
+        t = lambda a: torch.tensor(a, device=dev, requires_grad=True)
+        pc = t(inp["pc"][::rep].copy()) if rep > 1 else t(inp["pc"])
+        pose, scale = t(inp["pose"]), t(inp["scale"])
+        kw = dict(views_per_cloud=rep) if rep > 1 else {}
+        if fused:
+            out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale,
+                                                  silhouette_target=(gt, C, valid), **kw)
+            loss, win, err = out["proj_loss"], out["winning_pose_candidates"], out["proj_inst_err"]
+        else:
+            out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale, **kw)
+            loss, win, err = dpc_amd.ops.SilhouetteLoss.apply(out["proj"], gt, valid, C)
+        g = torch.autograd.grad(loss * 3.0, [pc, pose, scale])
+        res[fused] = (float(loss), win.cpu().numpy(), err.cpu().numpy(), [x.cpu().numpy() for x in g])
+    a, b = res[True], res[False]
+    assert abs(a[0] - b[0]) <= 1e-5 * abs(b[0]) and np.array_equal(a[1], b[1])
+    assert maxabs(a[2], b[2]) <= 1e-5 * float(np.abs(b[2]).max())
+    for x, y in zip(a[3], b[3]):
+        assert maxabs(x, y) <= 2e-5 * max(float(np.abs(y).max()), 1e-12)

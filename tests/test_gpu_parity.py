@@ -512,7 +512,11 @@ def test_graph_replay_follows_the_dropout_and_sigma_schedules():
         kern = dpc_amd.smoothing_kernel(cfg, dpc_amd.model_pc.get_smooth_sigma(cfg, step), device=dev)
         for a, b in zip(kern, projector.gauss_kernel()):
             assert torch.equal(a, b)                                      # the taps moved in place
-        eager = dpc_amd.pointcloud_project_fast(cfg, o["all_points"].detach(), o["poses"].detach(), None, None, kern,
+        # (the recorded step replicates inside the kernels; `all_points` of the captured dict would be built once, from
+        # the first replay's clouds, so the copies are made here from the clouds of THIS replay)
+        reps = cfg.step_size * cfg.pose_predict_num_candidates
+        all_points = torch.repeat_interleave(o["points_1"].detach(), reps, dim=0)
+        eager = dpc_amd.pointcloud_project_fast(cfg, all_points, o["poses"].detach(), None, None, kern,
                                                 scaling_factor=o["all_scaling_factors"].detach(),
                                                 point_dropout=(keep, seed))
         # bit for bit while the integer splat applies; a plane holding >= 4096 of the (untrained, clustered) points
@@ -714,3 +718,30 @@ dpc_amd.distributed.finalize()
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "WORST" in r.stdout
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(C=1, with_valid=False), dict(B=12, C=2, S=32, rep=3),
+                                dict(B=320, C=4, N=8000, D=64, K=21, S=128, rep=20),          # the training step's shape
+                                dict(B=32, C=4, N=4000, D=128, K=11, S=128)])
+def test_fused_candidate_loss(kw):
+    parity_cases.fused_candidate_loss_equals_the_image_epilogue("cuda", **kw)
+
+
+def test_views_per_cloud_on_device():
+    """in-kernel replication (tf_repeat_0 as an index) == explicit copies, at the training step's shape"""
+    import dpc_amd as d
+    Cc, R, N, D, K = 16, 20, 8000, 64, 21
+    inp = synth.make_inputs(Cc * R, N, 99)
+    cfg = d.default_config(vox_size=D, pc_gauss_kernel_size=K)
+    kern = d.smoothing_kernel(cfg, 3.0, device="cuda")
+    t = lambda a: torch.tensor(a, device="cuda", requires_grad=True)
+    w = torch.randn(Cc * R, D, D, 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    clouds, pose, scale = t(inp["pc"][::R].copy()), t(inp["pose"]), t(inp["scale"])
+    a = d.pointcloud_project_fast(cfg, clouds, pose, None, None, kern, scaling_factor=scale, views_per_cloud=R)
+    ga = torch.autograd.grad(a["proj"], [clouds, pose, scale], w)
+    clouds2, pose2, scale2 = t(inp["pc"][::R].copy()), t(inp["pose"]), t(inp["scale"])
+    b = d.pointcloud_project_fast(cfg, torch.repeat_interleave(clouds2, R, dim=0), pose2, None, None, kern, scaling_factor=scale2)
+    gb = torch.autograd.grad(b["proj"], [clouds2, pose2, scale2], w)
+    assert float((a["proj"] - b["proj"]).abs().max()) == 0.0
+    for x, y in zip(ga, gb):
+        assert float((x - y).abs().max()) <= 2e-5 * float(y.abs().max())

@@ -43,7 +43,7 @@ def test_struct_mirrors_match_the_library_layout():
     refuses a mismatch), and the nullable device pointer added in round 2 sits where C puts it."""
     lib = _capi.get_library()
     assert lib.dpc_abi_struct_bytes(0) == ctypes.sizeof(_capi.DpcShape) == 28
-    assert lib.dpc_abi_struct_bytes(1) == ctypes.sizeof(_capi.DpcParams) == 72
+    assert lib.dpc_abi_struct_bytes(1) == ctypes.sizeof(_capi.DpcParams) == 120
     assert lib.dpc_abi_struct_bytes(2) == 0
     assert _capi.DpcParams.dropout_state.offset == 40
     assert (_capi.DpcParams.l2_target.offset, _capi.DpcParams.l2_grad.offset, _capi.DpcParams.l2_weight.offset) == (48, 56, 64)

@@ -90,3 +90,8 @@ def test_emu_model_replicates_inside_the_kernels(emu):
         assert outputs["all_points"].shape == (8, 120, 3)                    # still there for whoever asks
     assert float((res[True][0] - res[False][0]).abs().max()) == 0.0
     assert float((res[True][1] - res[False][1]).abs().max()) <= 1e-6 * float(res[False][1].abs().max())
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(C=1, with_valid=False), dict(B=12, C=2, S=32, rep=3)])
+def test_emu_fused_candidate_loss(emu, kw):
+    parity_cases.fused_candidate_loss_equals_the_image_epilogue("cpu", **kw)
