@@ -745,3 +745,36 @@ def test_views_per_cloud_on_device():
     assert float((a["proj"] - b["proj"]).abs().max()) == 0.0
     for x, y in zip(ga, gb):
         assert float((x - y).abs().max()) <= 2e-5 * float(y.abs().max())
+
+
+def test_training_step_full_batch_fused_paths_equal_explicit_paths():
+    """BASELINE configs[2] at its FULL model batch (16 models x 5 views x 4 pose candidates = 320 instances of 8000
+    points, 64^3, K = 21): one step with the replication and the candidate loss inside the projector's kernels
+    (the default) against the same step with the explicit [320,8000,3] copies and the loss epilogue on the image --
+    same loss, same winning candidates, same parameter gradients."""
+    import os
+    import sys
+    ex = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "chair_unsupervised")
+    sys.path.insert(0, ex)
+    import train_step as ts
+    from nets import Im2PointCloud
+    dev = torch.device("cuda")
+    res = {}
+    for fused in (True, False):
+        cfg = ts.make_cfg(batch_size=16, pc_point_dropout=1.0, pc_replicate_in_kernel=fused, pc_fused_proj_loss=fused)
+        torch.manual_seed(0)
+        net = Im2PointCloud(cfg, 128).to(dev)
+        projector = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device=dev)
+        inputs = ts.synthetic_batch(cfg, dev, 128, seed=0)
+        outputs = projector.replicate_outputs(net(inputs["images"]))
+        outputs = projector.compute_projection(inputs, outputs, is_training=True)
+        assert outputs["projs"].shape == (320, 64, 64, 1)
+        assert ("_fused_proj_loss" in outputs) == fused and (outputs.points_replication() is not None) == fused
+        loss = projector.add_proj_loss(inputs, outputs, cfg.proj_weight)
+        loss.backward()
+        res[fused] = (float(loss), outputs["winning_pose_candidates"].cpu().numpy(),
+                      [p.grad.detach().clone() for p in net.parameters()])
+    assert abs(res[True][0] - res[False][0]) <= 1e-5 * abs(res[False][0])
+    assert np.array_equal(res[True][1], res[False][1])
+    for a, b in zip(res[True][2], res[False][2]):
+        assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1e-12)
