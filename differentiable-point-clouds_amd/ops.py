@@ -159,16 +159,6 @@ def _poison(t):
     return t
 
 
-class _Workspace(object):
-    """256-byte aligned scratch carved out of a torch allocation."""
-
-    def __init__(self, lib, shape, direction, like):
-        self.nbytes = lib.dpc_workspace_bytes(ctypes.byref(shape), direction)
-        self.buf = _poison(torch.empty((self.nbytes + 256 + 3) // 4, dtype=torch.float32, device=like.device))
-        base = self.buf.data_ptr()
-        self.ptr = ctypes.c_void_p((base + 255) & ~255)
-
-
 def _a256(n):
     return (n + 255) & ~255
 
@@ -233,10 +223,14 @@ def _at(base, off):
 # ---------------------------------------------------------------------------
 class ProjectFused(torch.autograd.Function):
     """pointcloud_project_fast as ONE autograd node: (pc, pose, trans, scale,
-    focal) -> (proj [B,D,D,1], proj_depth [B,D,D,1] | None, tr_pc [B,N,3], l2_grad [B,D,D,1] | None).
+    focal) -> (proj [B,D,D,1], proj_depth [B,D,D,1] | None, tr_pc [B,N,3], l2_grad [B,D,D,1] | None,
+    sil_loss [] | None, sil_winners [B/C] int64 | None, sil_inst_err [B] | None).
     l2_grad (meta.l2_target set) = l2_weight * (proj - l2_target), written by the collapse kernel itself:
     the gradient of 0.5 * l2_weight * sum((proj - target)^2) w.r.t. proj, ready to be passed back as
     grad_outputs; not differentiable.
+    sil_* (meta.sil_gt set): the candidate silhouette loss of model_pc.py:308-337 / 383-423 evaluated inside the
+    collapse kernels; sil_loss is differentiable -- its gradient w.r.t. proj is formed inside the backward kernels.
+    meta.views_per_cloud = R > 1: pc is [B/R,N,3] (instance b projects cloud b // R), dpc comes back per cloud.
 
     Host path: one cached plan per shape (_FusedPlan), three device allocations in forward (tr_pc; the images;
     one arena for everything saved for backward -- the kernels take raw pointers, so the arena is never cut
