@@ -97,7 +97,12 @@ FUSED_CASES_GPU = FUSED_CASES + [
     (1, 2000, 128, 128, 21, 3.0, False, False),  # K = 21 at 128^3
     (2, 300, 32, 32, 11, 1.2, False, False),     # smallest fused lattice
     (1, 1500, 128, 64, 11, 1.6, False, False),   # vox_size_z = vox_size / 2 at 128: Kz = 5
+    # round 3: one-strip planes with more than 128 points -> k_gather_yx's dense flow (x-blur adjoint in registers while staging)
+    (2, 6000, 32, 32, 21, 3.0, False, False),    # D = 32 (2 floats per lane), 21 taps: halo from 5 lanes away
+    (2, 8000, 64, 64, 11, 1.6, True, True),      # D = 64, 11 taps, with translation and focal length
+    (1, 8000, 64, 64, 5, 0.9, False, False),     # D = 64, 5 taps
 ]
+DENSE_GATHER_CASE_EMU = (1, 3000, 32, 32, 5, 0.8, False, False)    # ~150+ points per occupied plane at D = 32
 
 
 def _nudge_off_cell_faces(inp, trans, focal, Dz, D, tol=3e-5):

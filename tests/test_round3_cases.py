@@ -95,3 +95,9 @@ def test_emu_model_replicates_inside_the_kernels(emu):
 @pytest.mark.parametrize("kw", [dict(), dict(C=1, with_valid=False), dict(B=12, C=2, S=32, rep=3)])
 def test_emu_fused_candidate_loss(emu, kw):
     parity_cases.fused_candidate_loss_equals_the_image_epilogue("cpu", **kw)
+
+
+def test_emu_dense_gather_flow(emu):
+    """a one-strip plane with more than 128 points: k_gather_yx blurs whole rows (x in registers while staging, y from
+    the LDS tile) and every point reads its 2 x 2 cells -- against the float64 NumPy oracle"""
+    parity_cases.fused_path_against_numpy_oracle("cpu", *parity_cases.DENSE_GATHER_CASE_EMU)
