@@ -342,6 +342,7 @@ def main():
         # the host sets the pace.  The whole step -- nets, projector, loss epilogue, backward, (N > 1: the bucketed RCCL
         # all-reduce of the gradients, issued from gradient hooks and overlapped with the backward pass,) Adam -- is
         # recorded into ONE hipGraph per rank (the library only enqueues on the stream it is handed) and replayed.
+        # capture_error_mode thread_local: the RCCL watchdog thread may query events meanwhile.
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -355,13 +356,13 @@ def main():
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 case["graph_loss"] = case["run"]()
             run = graph.replay
-        except Exception as e:                       # noqa: BLE001 -- report, do not lose the measurement
-            if world == 1:
-                raise
-            torch.cuda.synchronize()
-            args.graph, graph_note = False, "HIP graph capture failed (%s: %s); eager launches" % (type(e).__name__, e)
-            sys.stderr.write("[rank %d] %s\n" % (rank, graph_note))
-            run = case["run"]
+        except Exception as e:                       # noqa: BLE001
+            # A capture that dies half way leaves the rank's streams in capture mode (seen with gloo on CUDA tensors,
+            # whose collectives fork streams that never join: hipErrorStreamCaptureUnjoined) -- there is no clean way on
+            # from here, and the other ranks are waiting in a collective: stop loudly instead of limping on.
+            sys.stderr.write("[rank %d] recording the training step failed (%s: %s); run without --graph for the eager "
+                             "DDP step\n" % (rank, type(e).__name__, e))
+            raise
     if args.graph and not train:
         # the library only enqueues on the stream it is handed, so a whole step (forward with the loss
         # gradient, backward) records into one hipGraph; replay costs one launch on the host.  Capture is
