@@ -44,7 +44,7 @@ def test_emu_views_per_cloud_equals_explicit_replication(emu):
     sum over each cloud's R instances."""
     import torch
     import dpc_amd
-    C, R, N, D, K = 2, 3, 150, 32, 5
+    C, R, N, D, K = 2, 3, 80, 32, 5
     inp = synth.make_inputs(C * R, N, 321)
     cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K)
     kern = dpc_amd.smoothing_kernel(cfg, 0.9, device="cpu")
@@ -74,11 +74,11 @@ def test_emu_model_replicates_inside_the_kernels(emu):
     import dpc_amd
     res = {}
     for in_kernel in (True, False):
-        cfg = dpc_amd.default_config(vox_size=32, pc_gauss_kernel_size=5, pc_num_points=120, predict_pose=True,
+        cfg = dpc_amd.default_config(vox_size=32, pc_gauss_kernel_size=5, pc_num_points=60, predict_pose=True,
                                      pose_predict_num_candidates=2, step_size=2, batch_size=2, pc_point_dropout=1.0,
                                      pc_replicate_in_kernel=in_kernel)
         m = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device="cpu")
-        inp = synth.make_inputs(2, 120, 5)
+        inp = synth.make_inputs(2, 60, 5)
         pts = torch.tensor(inp["pc"], requires_grad=True)
         poses = torch.tensor(synth.make_inputs(8, 4, 6)["pose"])
         outputs = m.replicate_outputs({"points_1": pts, "poses": poses, "scaling_factor": torch.full((2, 1), 0.8)})
@@ -87,12 +87,12 @@ def test_emu_model_replicates_inside_the_kernels(emu):
         assert (outputs.points_replication() is not None) == in_kernel       # the copies were only built on the explicit path
         g = torch.autograd.grad(outputs["projs"].sum(), [pts])[0]
         res[in_kernel] = (outputs["projs"].detach(), g)
-        assert outputs["all_points"].shape == (8, 120, 3)                    # still there for whoever asks
+        assert outputs["all_points"].shape == (8, 60, 3)                    # still there for whoever asks
     assert float((res[True][0] - res[False][0]).abs().max()) == 0.0
     assert float((res[True][1] - res[False][1]).abs().max()) <= 1e-6 * float(res[False][1].abs().max())
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(C=1, with_valid=False), dict(B=12, C=2, S=32, rep=3)])
+@pytest.mark.parametrize("kw", [dict(N=100), dict(B=4, C=1, N=100, with_valid=False), dict(B=6, C=2, N=100, S=32, rep=3)])
 def test_emu_fused_candidate_loss(emu, kw):
     parity_cases.fused_candidate_loss_equals_the_image_epilogue("cpu", **kw)
 
