@@ -331,7 +331,7 @@ def main():
             lo, hi = dd.shard_range(total, rank, world)          # this rank's contiguous slice of the global batch
             if hi - lo == 0:
                 raise SystemExit("--scaling strong: %d views do not split over %d ranks" % (total, world))
-            batch = hi - lo
+            batch, args.global_views = hi - lo, total
         case = build_case(args.config, batch, device, seed_offset=1000 * rank, kind=args.points, N=args.num_points)
         run = lambda: step(case)
     graph_note = None
@@ -476,7 +476,8 @@ def main():
                                   "*_of_ceiling: over the float4 copy measured in this run"}
 
     if rank == 0:
-        views = world * case["B"] * args.steps
+        global_views = getattr(args, "global_views", None) or world * case["B"]    # (strong scaling: uneven slices add up)
+        views = global_views * args.steps
         cfg_idx = {1: 0, 2: 1, 3: 2 if world == 1 else 3, 5: 4}[args.config]
         if train:
             workload = ("BASELINE.json configs[%d]: chair_unsupervised training step (encoder+decoder+pose nets, stock "
@@ -498,7 +499,7 @@ def main():
             "data": ("dry run on the CPU emulation library: NOT a measurement" if DRY_RUN else
                      "ranks share one GPU (DPC_BENCH_SHARE_GPU): NOT a measurement"
                      if os.environ.get("DPC_BENCH_SHARE_GPU") == "1" else "synthetic"),
-            "config": {"workload": workload, "global_batch": world * case["B"], "K": case["K"],
+            "config": {"workload": workload, "global_batch": global_views, "K": case["K"],
                        "hip_graph": bool(args.graph), **({"hip_graph_note": graph_note} if graph_note else {}),
                        "training_step": bool(train),
                        "parallelism": ("models sharded x%d (%s), gradient all-reduce over RCCL" % (world, case.get("reducer") or "DDP")) if train else
@@ -507,7 +508,7 @@ def main():
                 "repeats": len(blocks), "steps_per_block": args.steps, "clock": "HIP events, rank 0",
                 "ms_per_step_median": pctl(blocks, 50), "ms_per_step_p10": pctl(blocks, 10),
                 "ms_per_step_p90": pctl(blocks, 90),
-                "value_median": world * case["B"] / (pctl(blocks, 50) * 1e-3)},
+                "value_median": global_views / (pctl(blocks, 50) * 1e-3)},
             "roofline": roof,
         }
         if train:
