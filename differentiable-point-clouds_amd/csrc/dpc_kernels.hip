@@ -165,10 +165,8 @@ int dpc_silhouette_select(dpc_stream_t stream, int B, int C, int nparts, const f
   if (B <= 0 || C <= 0 || B % C != 0 || nparts <= 0) return DPC_E_SHAPE;
   if (!err_parts || !inst_err || !weight || !loss) return DPC_E_NULL;
   hipStream_t st = (hipStream_t)stream;
-  DPC_LAUNCH("sil_sum_parts", (k_sil_sum_parts), dim3((B + DPC_BLOCK - 1) / DPC_BLOCK, 1, 1), dim3(DPC_BLOCK, 1, 1), 0, st,
-             err_parts, inst_err, B, nparts);
-  DPC_LAUNCH("sil_select", (k_sil_select), dim3(1, 1, 1), dim3(DPC_BLOCK, 1, 1), 0, st, (const float*)inst_err, valid,
-             (int*)winners, weight, loss, B / C, C);
+  DPC_LAUNCH("sil_select", (k_sil_select_parts), dim3(1, 1, 1), dim3(DPC_BLOCK, 1, 1), 0, st, err_parts, nparts, valid,
+             inst_err, (int*)winners, weight, loss, B / C, C);
   return last_error();
 }
 
