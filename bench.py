@@ -22,7 +22,8 @@ one optimiser step).  The projector shards over instances with no data-path coll
 per GPU); ranks only meet at the timing barriers (config 3: plus DDP's gradient all-reduce).
 
 Rank 0 prints ONE JSON line.  `value` comes from EXACTLY --steps steps after --warmup untimed ones, bracketed
-by barrier + torch.cuda.synchronize() on both sides, max over ranks.  Besides the contract keys:
+by barrier + torch.cuda.synchronize() on both sides, max over ranks (--burn-in seconds of further untimed steps come
+BEFORE the warm-up steps, so that the clocks have settled: config.burn_in_s).  Besides the contract keys:
   timing       --repeats further blocks of --steps steps, each timed with HIP events: median / p10 / p90
   roofline     dominant projector kernel: algorithmic bytes per launch / its mean launch duration (HIP events
                on the launch stream, dpc_profile_*), against the 8 TB/s HBM3E peak AND against a float4 copy
@@ -275,6 +276,10 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): the config's batch PER GPU; strong: the config's batch split over the GPUs "
                          "(SURVEY.md 8(e): secondary, latency-bound at 8 GPUs)")
+    ap.add_argument("--burn-in", type=float, default=0.3,
+                    help="seconds of untimed steps BEFORE the --warmup steps: the GPU's clocks take ~0.1 s of continuous load to "
+                         "settle after the idle set-up phase (profiles/r03/startup_probe.txt); without it a 20-step timed block "
+                         "runs 4-8 %% below the steady state the `timing` blocks see.  0 = off.  Reported in config.burn_in_s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -387,6 +392,12 @@ def main():
             args.graph, graph_note = False, "HIP graph capture failed (%s: %s); eager launches" % (type(e).__name__, e)
             sys.stderr.write("[rank %d] %s\n" % (rank, graph_note))
             run = lambda: step(case)
+    if args.burn_in > 0 and not DRY_RUN:       # clocks up (see --burn-in); untimed, before the contract's warm-up steps
+        t_burn = time.perf_counter()
+        while time.perf_counter() - t_burn < args.burn_in:
+            for _ in range(8):
+                run()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         run()
     dd.barrier(device)                      # barrier + torch.cuda.synchronize() on both sides
@@ -501,6 +512,7 @@ def main():
                      if os.environ.get("DPC_BENCH_SHARE_GPU") == "1" else "synthetic"),
             "config": {"workload": workload, "global_batch": global_views, "K": case["K"],
                        "hip_graph": bool(args.graph), **({"hip_graph_note": graph_note} if graph_note else {}),
+                       "burn_in_s": 0.0 if DRY_RUN else args.burn_in,
                        "training_step": bool(train),
                        "parallelism": ("models sharded x%d (%s), gradient all-reduce over RCCL" % (world, case.get("reducer") or "DDP")) if train else
                                       ("views sharded x%d, no data-path collective" % world)},
