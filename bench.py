@@ -393,11 +393,17 @@ def main():
             sys.stderr.write("[rank %d] %s\n" % (rank, graph_note))
             run = lambda: step(case)
     if args.burn_in > 0 and not DRY_RUN:       # clocks up (see --burn-in); untimed, before the contract's warm-up steps
-        t_burn = time.perf_counter()
-        while time.perf_counter() - t_burn < args.burn_in:
-            for _ in range(8):
+        if train and world > 1:
+            # every step holds collectives: all ranks must run the SAME number of steps -- a count, not a clock
+            for _ in range(max(8, int(args.burn_in / 0.004))):
                 run()
             torch.cuda.synchronize()
+        else:
+            t_burn = time.perf_counter()
+            while time.perf_counter() - t_burn < args.burn_in:
+                for _ in range(8):
+                    run()
+                torch.cuda.synchronize()
     for _ in range(args.warmup):
         run()
     dd.barrier(device)                      # barrier + torch.cuda.synchronize() on both sides
