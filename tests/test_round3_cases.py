@@ -101,3 +101,55 @@ def test_emu_dense_gather_flow(emu):
     """a one-strip plane with more than 128 points: k_gather_yx blurs whole rows (x in registers while staging, y from
     the LDS tile) and every point reads its 2 x 2 cells -- against the float64 NumPy oracle"""
     parity_cases.fused_path_against_numpy_oracle("cpu", *parity_cases.DENSE_GATHER_CASE_EMU)
+
+
+def test_grad_buckets_partition_and_views():
+    """GradBuckets on one rank: every parameter's .grad is a view into exactly one flat bucket (reverse parameter order,
+    size limit respected, strides of the parameter kept), backward accumulates into the buckets in place, finish()
+    re-arms the countdown, zero_() clears what the next step accumulates into."""
+    import torch
+    import dpc_amd
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.LeakyReLU(), torch.nn.Conv2d(8, 4, 3), torch.nn.Flatten(),
+                              torch.nn.Linear(4 * 4 * 4, 16), torch.nn.Linear(16, 2))
+    net = net.to(memory_format=torch.channels_last)
+    params = list(net.parameters())
+    red = dpc_amd.distributed.GradBuckets(params, bucket_mb=2048 / (1 << 20))        # 2 KiB buckets: several of them
+    assert len(red.buckets) >= 3
+    seen = []
+    for flat, plist in red.buckets:
+        assert flat.numel() == sum(p.numel() for p in plist)
+        for p in plist:
+            assert p.grad is not None and p.grad.shape == p.shape and p.grad.stride() == p.stride()
+            assert p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+            seen.append(p)
+    assert [id(p) for p in seen] == [id(p) for p in reversed(params)]                  # reverse order, each exactly once
+    x = torch.randn(5, 3, 8, 8)
+    ref = torch.autograd.grad(net(x).square().sum(), params)
+    for step in range(2):                                                              # second step: after zero_()
+        net(x).square().sum().backward()
+        red.finish()
+        for p, g in zip(params, ref):
+            assert torch.allclose(p.grad, g, rtol=1e-6, atol=1e-7)
+        assert all(n == len(pl) for n, (_, pl) in zip(red._pending, red.buckets))      # re-armed
+        red.zero_()
+        assert all(float(p.grad.abs().max()) == 0.0 for p in params)
+
+
+def test_replicated_outputs_is_lazy_and_dict_like():
+    """ModelPointCloud.replicate_outputs: `all_points` is built on first read only, exactly as tf_repeat_0 would, and
+    an explicit assignment (a caller replacing the clouds) wins over the lazy value."""
+    import torch
+    import dpc_amd
+    mp = dpc_amd.model_pc
+    pts = torch.arange(2 * 3 * 3, dtype=torch.float32).reshape(2, 3, 3)
+    out = mp.ReplicatedOutputs({"points_1": pts, "x": 1}, 3)
+    assert out.points_replication() is not None and out.points_replication()[1] == 3 and "all_points" in out
+    assert out["x"] == 1 and out.points_replication() is not None                       # other keys do not materialise it
+    ap = out["all_points"]
+    assert out.points_replication() is None and torch.equal(ap, mp.tf_repeat_0(pts, 3)) and out["all_points"] is ap
+    out2 = mp.ReplicatedOutputs({"points_1": pts}, 2)
+    out2["all_points"] = pts[:1]
+    assert out2.points_replication() is None and out2.get("all_points").shape == (1, 3, 3)
+    out3 = mp.ReplicatedOutputs({"points_1": pts}, 2)
+    assert dict(out3.items())["all_points"].shape == (4, 3, 3)                          # items() / values() materialise
