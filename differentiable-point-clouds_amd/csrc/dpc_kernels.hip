@@ -48,30 +48,12 @@
 // The same source compiles for the CPU-only test tier with -DDPC_EMU (see
 // tests/hipemu/hip_emu.h); that build is never loaded by the product.
 
-#include "dpc_hip.h"
-
-#ifdef DPC_EMU
-#include "hip_emu.h"  // tests/hipemu: a thread-per-lane model of the HIP API used below (CPU test tier only)
-#else
-#include <hip/hip_runtime.h>
-#include "k_asm_gfx950.inc"   // the few instructions hipcc will not pick on its own (tests/hipemu/hip_emu.h restates them)
-#endif
-
-// dynamic LDS of the kernel as a typed pointer (16-byte aligned base)
-#define DPC_DYN_SMEM(type, name)                     \
-  HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) unsigned char, name##_raw) \
-  type* name = reinterpret_cast<type*>(name##_raw)
-
-#include <math.h>
+#include "k_prelude.inc"
 
 #include <mutex>
 #include <vector>
 
-// ---------------------------------------------------------------------------
-// optional per-kernel timing: HIP events recorded on the launch stream around
-// every launch while enabled (bench.py's roofline leg).  Off by default; not
-// meant for concurrent use from several threads.
-// ---------------------------------------------------------------------------
+// per-kernel timing (declared in k_prelude.inc; the one definition of the whole library)
 namespace dpcprof {
 struct Rec {
   const char* label;
@@ -80,7 +62,7 @@ struct Rec {
 static std::mutex g_mu;
 static bool g_on = false;
 static std::vector<Rec> g_recs;
-static inline bool begin(const char* label, hipStream_t st) {
+bool begin(const char* label, hipStream_t st) {
   if (!g_on) return false;
   std::lock_guard<std::mutex> lk(g_mu);
   Rec r;
@@ -90,7 +72,7 @@ static inline bool begin(const char* label, hipStream_t st) {
   g_recs.push_back(r);
   return true;
 }
-static inline void end(hipStream_t st) {
+void end(hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_mu);
   (void)hipEventRecord(g_recs.back().b, st);
 }
@@ -104,26 +86,9 @@ static inline void clear() {
 }
 }  // namespace dpcprof
 
-#define DPC_LAUNCH(label, kernel, grid, block, smem, stream, ...)          \
-  do {                                                                     \
-    const bool prof_ = dpcprof::begin(label, stream);                      \
-    hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);    \
-    if (prof_) dpcprof::end(stream);                                       \
-  } while (0)
-
-static inline hipError_t dpc_memset(const char* label, void* p, size_t n, hipStream_t st) {
-  const bool prof_ = dpcprof::begin(label, st);
-  hipError_t e = hipMemsetAsync(p, 0, n, st);
-  if (prof_) dpcprof::end(st);
-  return e;
-}
-
-#define DPC_BLOCK 256
-#define DPC_XC 8  // x-blur outputs per thread (register window)
-#define DPC_YC 8  // y-blur outputs per thread
-
 // ---------------------------------------------------------------------------
-// the kernels and their launchers, one translation unit (order matters: later files use earlier ones)
+// the kernels and their launchers (order matters: later files use earlier ones).  The kernels that are unrolled for a
+// compile-time tap count are only DECLARED to this unit (host_launch_k.inc); tu_taps.hip compiles them, one unit per K.
 // ---------------------------------------------------------------------------
 #include "k_device_common.inc"
 #include "k_points.inc"
@@ -132,6 +97,7 @@ static inline hipError_t dpc_memset(const char* label, void* p, size_t n, hipStr
 #include "k_blur_stream.inc"
 #include "k_fused.inc"
 #include "k_zpass.inc"
+#include "host_launch_k.inc"
 #include "host_launch.inc"
 #include "k_extras.inc"
 
@@ -156,7 +122,8 @@ int dpc_saved_layout(const DpcShape* shape, const DpcParams* params) {
 }
 
 size_t dpc_sil_parts_per_view(const DpcShape* shape) {
-  if (check_shape(shape, true) != DPC_OK || !splat_plan(*shape).ok) return 0;
+  // (the epilogue lives in the fused collapse kernels: fused front end, a compile-time z tap count, whole work-groups)
+  if (check_shape(shape, true) != DPC_OK || !splat_plan(*shape).ok || !z_fixed(shape->Kz)) return 0;
   return ((size_t)shape->D * shape->D / pick_cx(shape->D)) % DPC_BLOCK == 0 ? (size_t)zbwd_blocks(*shape) : 0;
 }
 

@@ -98,7 +98,18 @@ class GradBuckets(object):
 
     Averaging matches DDP: sum over ranks, divided by the world size.  Works with any backend (the gloo tests
     check it against a single process on the concatenated batch); with one rank it degenerates to plain
-    accumulation into the flat buffers."""
+    accumulation into the flat buffers.
+
+    Invariants, checked (a violation would otherwise let the ranks diverge silently):
+    * every p.grad must still BE its bucket view when finish() runs -- optimizer.zero_grad() (set_to_none=True by
+      default) or backward(create_graph=True) replace it, after which the hooks would reduce stale buffers:
+      finish() raises;
+    * ONE backward pass per finish(): a second one would drive a bucket's count negative (its all-reduce has
+      already been issued with the first pass's gradients): the hook raises.  Accumulate into the buckets by
+      calling finish() once per micro-step, or scale the loss instead;
+    * the collectives are issued in BUCKET ORDER on every rank (a bucket whose gradients are complete waits for
+      the buckets before it), so ranks whose autograd graphs finish buckets in different orders -- or leave
+      different parameters without a gradient -- still issue matching all-reduces."""
 
     def __init__(self, params, bucket_mb=64, process_group=None):
         self.group = process_group
@@ -119,6 +130,8 @@ class GradBuckets(object):
             self._close(cur)
         self._pending = [0] * len(self.buckets)
         self._works = []
+        self._next = 0                 # first bucket whose all-reduce has not been issued in this step
+        self._views = [(p, p.grad.data_ptr()) for _, plist in self.buckets for p in plist]
         for p in params:
             p.register_post_accumulate_grad_hook(self._hook)
         self._arm()
@@ -138,19 +151,33 @@ class GradBuckets(object):
     def _arm(self):
         for i, (_, plist) in enumerate(self.buckets):
             self._pending[i] = len(plist)
+        self._next = 0
+
+    def _issue_ready(self, force=False):
+        """issue, in bucket order, the all-reduce of every leading bucket that is complete (force: of all that are left)"""
+        while self._next < len(self.buckets) and (force or self._pending[self._next] == 0):
+            if self.world > 1:
+                self._works.append(dist.all_reduce(self.buckets[self._next][0], group=self.group, async_op=True))
+            self._next += 1
 
     def _hook(self, p):
         i = self._of[p]
         self._pending[i] -= 1
-        if self._pending[i] == 0 and self.world > 1:
-            self._works.append(dist.all_reduce(self.buckets[i][0], group=self.group, async_op=True))
+        if self._pending[i] < 0:
+            raise RuntimeError("GradBuckets: a parameter received a second gradient before finish() -- one backward "
+                               "pass per finish() (its bucket's all-reduce has already been issued)")
+        if self._pending[i] == 0:
+            self._issue_ready()
 
     def finish(self):
         """wait (stream-wise) for the bucket collectives and turn the sums into averages; re-arm for the next step"""
+        for p, ptr in self._views:
+            if p.grad is None or p.grad.data_ptr() != ptr:
+                raise RuntimeError("GradBuckets: the .grad of a parameter is no longer its bucket view (optimizer.zero_grad() "
+                                   "sets it to None by default -- use buckets.zero_(); backward(create_graph=True) replaces "
+                                   "it): the buckets hold stale gradients")
+        self._issue_ready(force=True)        # buckets with parameters that received no gradient this step: reduce anyway
         if self.world > 1:
-            for i, n in enumerate(self._pending):    # parameters that received no gradient this step: reduce anyway
-                if n > 0:
-                    self._works.append(dist.all_reduce(self.buckets[i][0], group=self.group, async_op=True))
             for w in self._works:
                 w.wait()
             for flat, _ in self.buckets:

@@ -65,6 +65,26 @@ class ReplicatedOutputs(dict):
         self["all_points"]
         return dict.values(self)
 
+    # dict(outputs), {**outputs} and outputs.copy() read a dict subclass's storage directly unless __iter__ is
+    # overridden (CPython's dict_merge fast path): route them through __getitem__ so that they see the real tensor
+    def __iter__(self):
+        return dict.__iter__(self)
+
+    def copy(self):
+        return dict(self.items())
+
+    def pop(self, k, *default):
+        if k == "all_points" and k in self:
+            self[k]
+        return dict.pop(self, k, *default)
+
+    def popitem(self):
+        self["all_points"]
+        return dict.popitem(self)
+
+    def setdefault(self, k, default=None):
+        return self[k] if k in self else dict.setdefault(self, k, default)
+
 
 def get_smooth_sigma(cfg, global_step):
     """model_pc.py:35-40: linear anneal pc_relative_sigma -> pc_relative_sigma_end."""
@@ -168,10 +188,11 @@ class ModelPointCloud(object):
     def get_dropout_keep_prob(self):
         return get_dropout_prob(self.cfg(), self._global_step)
 
-    def _fused_path_ok(self, B, N, device, all_rgb):
+    def _fused_path_ok(self, B, N, device, all_rgb, need_sil=False):
         """True when pointcloud_project_fast takes the fused front/back end for B instances of N points (the path
         that implements the in-kernel dropout and replication): fast projector, no colour channels, and a loss set
-        that does not fetch the dense grids through the stage-level kernels."""
+        that does not fetch the dense grids through the stage-level kernels.  need_sil: also the candidate-loss
+        epilogue of the collapse kernels (whole work-groups per view, a compile-time z tap count)."""
         cfg = self.cfg()
         if not cfg.pc_fast or all_rgb is not None:
             return False
@@ -180,7 +201,10 @@ class ModelPointCloud(object):
         from .util.point_cloud import _flat_taps, _meta
         taps = _flat_taps(cfg, self.gauss_kernel(), device)
         K = tuple(0 if t is None else int(t.numel()) for t in taps)
-        return ops.uses_fused_path(ops._capi.get_library(), B, N, _meta(cfg), K)
+        lib = ops._capi.get_library()
+        if not ops.uses_fused_path(lib, B, N, _meta(cfg), K):
+            return False
+        return not need_sil or ops.fused_plan_for(lib, B, N, _meta(cfg), K).sil_parts > 0
 
     def _fused_dropout_ok(self, all_points, all_rgb, views_per_cloud=1):
         """The fused draw needs the fused path (cfg.pc_fused_dropout=False forces the explicit gather)."""
@@ -291,7 +315,9 @@ class ModelPointCloud(object):
             outputs["drc_probs"] = proj_out["drc_probs"] if getattr(cfg, "drc_weight", 0.0) else None
             outputs["projs_depth"] = proj_out["proj_depth"]
         else:                                                                # model_pc.py:250-253
-            proj, _voxels = pointcloud_project(cfg, outputs["all_points"], camera_pose, self.gauss_sigma())
+            # the (possibly dropped-out) local cloud, as the reference does; views_per_cloud is never set here
+            # (_fused_path_ok is False without pc_fast), so all_points is the materialised [B,N',3] tensor
+            proj, _voxels = pointcloud_project(cfg, all_points, camera_pose, self.gauss_sigma())
             outputs["projs_rgb"] = None
             outputs["projs_depth"] = None
         outputs["projs"] = proj
@@ -309,13 +335,17 @@ class ModelPointCloud(object):
         masks = inputs.get("masks") if hasattr(inputs, "get") else None
         if masks is None or cfg.pc_gauss_filter_gt or masks.dim() != 4 or masks.shape[1] < cfg.vox_size:
             return None
+        # what ProjectFused / dpc_project_forward enforce: square single-channel masks (anything else takes the
+        # SilhouetteLoss epilogue on `projs`, which raises its own errors for shapes the reference rejects too)
+        if masks.shape[1] != masks.shape[2] or masks.shape[3] != 1:
+            return None
         if masks.shape[1] > cfg.vox_size and cfg.bicubic_gt_downsampling:
             return None
         B = all_points.shape[0] * views_per_cloud
         C = cfg.pose_predict_num_candidates
         if B % C != 0 or masks.shape[0] != B // C:
             return None
-        if not self._fused_path_ok(B, all_points.shape[1], all_points.device, all_rgb):
+        if not self._fused_path_ok(B, all_points.shape[1], all_points.device, all_rgb, need_sil=True):
             return None
         valid = inputs["valid_samples"] if (cfg.variable_num_views and C > 1) else None
         return masks, C, valid

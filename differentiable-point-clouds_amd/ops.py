@@ -210,6 +210,12 @@ def _fused_plan(lib, B, N, meta, K):
     return plan
 
 
+def fused_plan_for(lib, B, N, meta, K):
+    """the cached per-shape plan (which buffers are saved, whether the candidate-loss epilogue applies, ...)"""
+    return _fused_plan(lib, B, N, meta._replace(l2_target=None, dropout_state=None, views_per_cloud=0, sil_gt=None,
+                                                 sil_valid=None), K)
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -232,8 +238,8 @@ class ProjectFused(torch.autograd.Function):
     collapse kernels; sil_loss is differentiable -- its gradient w.r.t. proj is formed inside the backward kernels.
     meta.views_per_cloud = R > 1: pc is [B/R,N,3] (instance b projects cloud b // R), dpc comes back per cloud.
 
-    Host path: one cached plan per shape (_FusedPlan), three device allocations in forward (tr_pc; the images;
-    one arena for everything saved for backward -- the kernels take raw pointers, so the arena is never cut
+    Host path: one cached plan per shape (_FusedPlan), a handful of device allocations in forward (tr_pc; one per
+    image -- independent tensors, so in-place edits of an output are legal; one arena for everything saved for backward -- the kernels take raw pointers, so the arena is never cut
     into tensor views) plus the workspace, and pointers passed to ctypes as plain integers."""
 
     @staticmethod
@@ -280,20 +286,19 @@ class ProjectFused(torch.autograd.Function):
             if sval is not None and (sval.numel() != B // C or sval.dtype != torch.float32 or not sval.is_contiguous()
                                      or sval.device != dev):
                 raise ValueError("valid_samples must be %d contiguous float32 values on the points' device" % (B // C))
-        n_img = plan.n_out + (1 if tgt is not None else 0)
-        imgs = torch.empty(n_img, B, D, D, 1, dtype=torch.float32, device=dev)      # proj | proj_depth | l2_grad
+        # the images are separate allocations (not views of one): autograd refuses in-place edits of views made
+        # inside a custom Function, and a caller holding `proj` must not pin `proj_depth`
+        new_img = lambda: _poison(torch.empty(B, D, D, 1, dtype=torch.float32, device=dev))
+        proj = new_img()
+        depth = new_img() if plan.drc else None
+        l2_grad = new_img() if tgt is not None else None
         tr_pc = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
         arena = torch.empty(plan.arena_bytes, dtype=torch.uint8, device=dev)
         work = torch.empty(plan.ws_fwd + 256, dtype=torch.uint8, device=dev)
         if _POISON:
-            imgs.fill_(float("nan"))
             tr_pc.fill_(float("nan"))
             arena.fill_(255)                   # 0xffffffff is a NaN, 0xff..ff a NaN double
             work.fill_(255)
-        views = imgs.unbind(0)
-        proj = views[0]
-        depth = views[1] if plan.drc else None
-        l2_grad = views[plan.n_out] if tgt is not None else None
         if sgt is not None:
             err_parts = torch.empty(B, plan.sil_parts, dtype=torch.float32, device=dev)
             sil = (sgt.data_ptr(), err_parts.data_ptr(), None, None, None, int(meta.sil_C), int(sgt.shape[1]))

@@ -189,6 +189,19 @@ class ProjectionOutputs(dict):
             self._materialise(k)
         return dict.values(self)
 
+    # dict(out), {**out}, out.copy(): CPython copies a dict subclass's storage directly unless __iter__ is overridden;
+    # with it the conversions go through __getitem__ and see the materialised entries
+    def __iter__(self):
+        return dict.__iter__(self)
+
+    def copy(self):
+        return dict(self.items())
+
+    def pop(self, k, *default):
+        if k in self._LAZY and k in self:
+            self._materialise(k)
+        return dict.pop(self, k, *default)
+
 
 def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
                             all_rgb, kernel=None, scaling_factor=None, focal_length=None, *, point_dropout=None,

@@ -21,7 +21,7 @@ def pytest_configure(config):
     import subprocess
     lib = os.path.join(ROOT, "differentiable-point-clouds_amd", "csrc", "libdpc_hip.so")
     if not os.path.exists(lib) and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
-        subprocess.check_call(["make", "-s", "-C", os.path.dirname(lib)])
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.dirname(lib)])
 
 
 def pytest_collection_modifyitems(config, items):
@@ -44,7 +44,7 @@ def emu_library():
     compiled with g++ against a thread-per-lane HIP model.  Test-only."""
     import subprocess
     emu_dir = os.path.join(ROOT, "tests", "hipemu")
-    subprocess.check_call(["make", "-s", "-C", emu_dir])
+    subprocess.check_call(["make", "-s", "-j8", "-C", emu_dir])
     import dpc_amd
     return dpc_amd._capi.DpcLibrary(os.path.join(emu_dir, "libdpc_emu.so"), host_memory=True)
 
