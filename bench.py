@@ -25,13 +25,16 @@ Rank 0 prints ONE JSON line.  `value` comes from EXACTLY --steps steps after --w
 by barrier + torch.cuda.synchronize() on both sides, max over ranks (--burn-in seconds of further untimed steps come
 BEFORE the warm-up steps, so that the clocks have settled: config.burn_in_s).  Besides the contract keys:
   timing       --repeats further blocks of --steps steps, each timed with HIP events: median / p10 / p90
-  roofline     dominant projector kernel: algorithmic bytes per launch / its mean launch duration (HIP events
-               on the launch stream, dpc_profile_*), against the 8 TB/s HBM3E peak AND against a float4 copy
-               measured in this run (copy_ceiling, frac_of_ceiling); traffic = PMC-measured HBM bytes of that
-               launch (profiles/traffic.json), measured_achieved = traffic / duration.  step_* = the projector's
-               whole fwd+bwd: step_alg_bytes is SURVEY.md 8(d)'s stage MODEL (8 V + P per view: an unfused
-               pipeline's compulsory traffic), step_alg_bytes_impl what THIS implementation has to move (5 V + P
-               when the xy-blurred grid is what is saved, 6 V + P otherwise), step_measured_bytes the PMC sum
+  roofline     dominant projector kernel: the bytes THIS implementation must move in that launch (grids: occupied
+               planes only, counted from this run's own point clouds; point records, images) / its mean launch
+               duration (HIP events on the launch stream, dpc_profile_*) = `achieved`, over the 8 TB/s HBM3E peak =
+               `frac` (a physical fraction, never above 1).  `ceilings`: a read-only, a write-only and a copy stream
+               over 512 MiB measured in this run; `vs_ceiling` = achieved over the mix of those that matches the
+               kernel's read / write split.  `traffic` = PMC-measured HBM bytes of that launch from
+               profiles/traffic.json -- only when that file was taken on the very library being timed (sha256
+               stamp), else null with a note.  step_* = the same for the projector's whole fwd+bwd.  `model` =
+               SURVEY.md 8(d)'s stage model (8 V + P per view: what an UNFUSED pipeline has to move), kept for
+               reference: its rates describe a pipeline this is not and may exceed the peak
   cpu_baseline oracle/reference_cpu.py (op-for-op torch-CPU restatement of the reference graph, kind "port")
                on a bounded sample on this host's cores (rank 0, N = 1 only)
 """
@@ -57,9 +60,10 @@ DRY_RUN = os.environ.get("DPC_BENCH_DRY_RUN") == "1"   # tests only: CPU emulati
 dpc_amd.synthetic.CONFIGS.setdefault(3, dict(B=320, N=8000, D=64, K=21, sigma=3.0))
 
 
-def build_case(cfg_id, B, device, seed_offset=0, kind="shell", N=None):
-    if N is not None:
-        dpc_amd.synthetic.CONFIGS[cfg_id] = dict(dpc_amd.synthetic.CONFIGS[cfg_id], N=int(N))
+def build_case(cfg_id, B, device, seed_offset=0, kind="shell", N=None, sigma=None, K=None, D=None):
+    over = {k: v for k, v in (("N", N), ("sigma", sigma), ("K", K), ("D", D)) if v is not None}
+    if over:
+        dpc_amd.synthetic.CONFIGS[cfg_id] = dict(dpc_amd.synthetic.CONFIGS[cfg_id], **over)
     c = dpc_amd.synthetic.config_inputs(cfg_id, B=B, kind=kind, seed_offset=seed_offset)
     cfg = dpc_amd.default_config(vox_size=c["D"], pc_gauss_kernel_size=c["K"])
     t = lambda a: torch.tensor(a, device=device, requires_grad=True)
@@ -90,6 +94,8 @@ def build_train_case(args, device, rank, world):
         toy = dict(vox_size=32, pc_gauss_kernel_size=5, pc_relative_sigma=0.9, pc_num_points=150, step_size=2,
                    pose_predict_num_candidates=2)
         net_kw = dict(f_dim=4, fc_dim=32, z_dim=32)
+    if args.sigma is not None:
+        toy = dict(toy, pc_relative_sigma=args.sigma)
     cfg = ts.make_cfg(batch_size=models, pc_point_dropout=args.keep_prob, pc_point_dropout_scheduled=False, **toy)
     torch.manual_seed(0)
     net = Im2PointCloud(cfg, image, **net_kw).to(device)
@@ -111,33 +117,59 @@ def build_train_case(args, device, rank, world):
     inputs = ts.synthetic_batch(cfg, device, image, seed=rank)
     views = cfg.batch_size * cfg.step_size * cfg.pose_predict_num_candidates
     if args.graph and not DRY_RUN:
-        projector.enable_graph_replay()        # blur taps and the dropout's {keep, seed} at fixed device addresses
+        projector.enable_graph_replay(follow_tap_counts=True)   # blur taps and the dropout's {keep, seed} at fixed device addresses
     case = dict(B=views, N=int(cfg.pc_num_points * args.keep_prob), D=cfg.vox_size, K=cfg.pc_gauss_kernel_size,
                 sigma=cfg.pc_relative_sigma, models=models, params=sum(p.numel() for p in net.parameters()),
                 views_per_model=cfg.step_size, candidates=cfg.pose_predict_num_candidates,
-                reducer="GradBuckets" if buckets is not None else ("DDP" if world > 1 else None),
+                reducer="GradBuckets" if buckets is not None else ("DDP" if world > 1 else None), projector=projector,
                 run=lambda: ts.train_step(model, projector, inputs, opt, world, buckets=buckets))
     return case
 
 
-def kernel_algorithmic_bytes(label, case, save_xy):
-    """Compulsory HBM bytes of ONE launch over the batch (DESIGN.md 'Kernels'):
-    every dense kernel reads one grid and writes one grid (2 V per view); the
-    zero-fill writes one (1 V); point kernels move O(N) bytes + their atomics."""
-    V = 4 * case["D"] ** 3
-    B, N = case["B"], case["N"]
-    # save_xy (fused path): k_zfwd only reads (the xy-blurred grid is what is saved), k_zbwd reads it + writes one
-    dense = {"zfwd": (V if save_xy else 2 * V), "zbwd": 2 * V, "blur_plane": 2 * V, "blur_xy": 2 * V,
-             "blur_z": 2 * V, "memset_grid": V, "splat_xy": V, "gather_yx": V}
-    if label in dense:
-        return B * dense[label]
-    if label == "points_fwd":
-        return B * (N * 24 + 8 * N * 8)
-    if label == "points_bwd":
-        return B * N * 88          # partials 48 + pc 12 + tr_pc 12 + slot 4 read, dpc 12 written
-    if label in ("zsort", "zhist", "zscatter"):
-        return B * N * 44          # pc 12 read; tr_pc 12 + record 16 + slot 4 written (whole sort, either form)
-    return 0
+def plane_occupancy(case):
+    """Occupied planes per view (k_splat_xy writes, k_zfwd / k_zbwd / k_gather_yx read only planes that hold trilinear
+    mass: a valid point in depth cell z-1 or z), counted on the host from one forward call's tr_pc -- so that the byte
+    counts below are what the kernels have to move for THESE clouds, not a dense-grid model."""
+    with torch.no_grad():
+        out = dpc_amd.pointcloud_project_fast(case["cfg"], case["pc"], case["pose"], None, None, case["kern"],
+                                              scaling_factor=case["scale"])
+        tr = out["tr_pc"].detach().cpu().numpy().astype(np.float32)
+    D = case["D"]
+    valid = np.all((tr >= -0.5) & (tr <= 0.5), axis=-1)
+    iz = np.floor((tr[..., 0] + np.float32(0.5)) * np.float32(D - 1)).astype(np.int64).clip(0, D - 1)
+    live = 0
+    for b in range(tr.shape[0]):
+        cells = np.zeros(D + 1, dtype=bool)
+        cells[iz[b][valid[b]]] = True
+        live += int((cells[:D] | np.concatenate([[False], cells[:D - 1]])).sum())
+    return live, int(valid.sum())
+
+
+def kernel_bytes(label, case, save_xy, occ):
+    """(read, written) HBM bytes THIS implementation must move in one launch of `label` over the batch (DESIGN.md
+    'Kernels').  occ = (occupied planes summed over the views, valid points) or None (dense model: every plane)."""
+    B, N, D = case["B"], case["N"], case["D"]
+    plane = 4 * D * D
+    L = occ[0] if occ else B * D                     # planes that exist
+    img = B * plane                                  # one [B,D,D] image
+    fused = {
+        # points 12 B in; tr_pc 12 + record 16 + slot 4 out
+        "zsort": (B * N * 12, B * N * 32), "zhist": (B * N * 12, B * N * 16), "zscatter": (B * N * 16, B * N * 20),
+        # every point's record is read by the two planes it touches; 4 clip bytes per point; occupied planes out
+        "splat_xy": (B * N * 32, L * plane + B * N * 4),
+        # occupied planes in (+ all of G2 out at > 11 taps); proj, depth, loss gradient (+ its target in), fp64 sums
+        "zfwd": (L * plane + img, (0 if save_xy else B * D * plane) + 3 * img + 4 * img),
+        "zbwd": ((L if save_xy else B * D) * plane + 4 * img + img, L * plane),
+        # occupied planes + records + clip bytes in; 12-byte partials out (2 or 4 per point)
+        "gather_yx": (L * plane + B * N * 32 + B * N * 4, B * N * 12 * (2 if D <= 64 else 4)),
+        "points_bwd": (B * N * (12 * (2 if D <= 64 else 4) + 12 + 12 + 4), B * N * 12),
+    }
+    if label in fused:
+        return fused[label]
+    V = D * plane
+    generic = {"memset_grid": (0, B * V), "points_fwd": (B * N * 12, B * N * 12 + B * N * 8 * 8),
+               "blur_plane": (B * V, B * V), "blur_xy": (B * V, B * V), "blur_z": (B * V, B * V)}
+    return generic.get(label, (0, 0))
 
 
 def _cpu_model():
@@ -202,39 +234,113 @@ def cpu_baseline(cfg_id, seconds_budget=20.0):
             "host_cpus": ncpu, "cpu_model": _cpu_model()}
 
 
-def copy_ceiling(lib, device, mbytes=512, reps=20):
-    """On-box HBM ceiling: the best of the library's float4 streaming copies (one, 4 or 8 loads in
-    flight per lane, default or nontemporal policy) and torch's own device copy, over buffers far larger than the
-    256 MiB Infinity Cache, timed with HIP events on the launch stream."""
+def hbm_ceilings(lib, device, mbytes=512, reps=20):
+    """On-box HBM ceilings, each the best of a few variants over buffers far larger than the 256 MiB
+    Infinity Cache, timed with HIP events on the launch stream: `read` (float4 loads summed per work-group, 4 or 8
+    in flight per lane, default or nontemporal policy; torch's own sum()), `write` (float4 fill, default or
+    nontemporal; torch's fill_()), `copy` (read + write: the library's float4 copies and torch's copy_)."""
     import ctypes
     n = mbytes * (1 << 20) // 4
     src = torch.empty(n, dtype=torch.float32, device=device).normal_()
     dst = torch.empty_like(src)
+    partials = torch.empty(8192, dtype=torch.float32, device=device)
     st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    ck = lib.check
+    groups = {
+        "read": (n * 4, {"float4 x4 in flight": lambda: ck(lib.dpc_debug_read(st, P(src), n, P(partials), 4), "read"),
+                         "float4 x8 in flight": lambda: ck(lib.dpc_debug_read(st, P(src), n, P(partials), 8), "read"),
+                         "float4 x4, nontemporal": lambda: ck(lib.dpc_debug_read(st, P(src), n, P(partials), 104), "read"),
+                         "float4 x8, nontemporal": lambda: ck(lib.dpc_debug_read(st, P(src), n, P(partials), 108), "read"),
+                         "torch sum()": lambda: src.sum()}),
+        "write": (n * 4, {"float4": lambda: ck(lib.dpc_debug_fill(st, P(dst), n, 1.0, 0), "fill"),
+                          "float4, nontemporal": lambda: ck(lib.dpc_debug_fill(st, P(dst), n, 1.0, 100), "fill"),
+                          "torch fill_()": lambda: dst.fill_(1.0)}),
+        "copy": (2 * n * 4, {"k_copy<4>": lambda: ck(lib.dpc_debug_copy(st, P(src), P(dst), n, 4), "copy"),
+                             "float4 x4 in flight": lambda: ck(lib.dpc_debug_copy(st, P(src), P(dst), n, 44), "copy"),
+                             "float4 x8 in flight": lambda: ck(lib.dpc_debug_copy(st, P(src), P(dst), n, 48), "copy"),
+                             "float4 x4, nontemporal": lambda: ck(lib.dpc_debug_copy(st, P(src), P(dst), n, 144), "copy"),
+                             "float4 x8, nontemporal": lambda: ck(lib.dpc_debug_copy(st, P(src), P(dst), n, 148), "copy"),
+                             "torch copy_": lambda: dst.copy_(src)}),
+    }
+    out = {"unit": "GB/s", "method": "%d MiB buffers, mean of %d launches per variant, HIP events; the fastest variant of "
+                                     "each kind is the ceiling" % (mbytes, reps)}
+    for kind, (nbytes, variants) in groups.items():
+        rates = {}
+        for name, call in variants.items():
+            for _ in range(3):
+                call()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                call()
+            e1.record()
+            e1.synchronize()
+            rates[name] = nbytes / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9
+        best = max(rates, key=rates.get)
+        out[kind] = rates[best]
+        out[kind + "_variant"] = best
+        out[kind + "_all"] = {k: round(v, 1) for k, v in rates.items()}
+    return out
 
-    def lib_copy(width):
-        return lambda: lib.check(lib.dpc_debug_copy(st, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()),
-                                                    n, width), "dpc_debug_copy")
 
-    variants = {"k_copy<4>": lib_copy(4), "float4 x4 in flight": lib_copy(44), "float4 x8 in flight": lib_copy(48),
-                "float4 x4, nontemporal": lib_copy(144), "float4 x8, nontemporal": lib_copy(148),
-                "torch copy_": lambda: dst.copy_(src)}
-    rates = {}
-    for name, call in variants.items():
-        for _ in range(3):
-            call()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            call()
-        e1.record()
-        e1.synchronize()
-        rates[name] = 2.0 * n * 4 / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9
-    best = max(rates, key=rates.get)
-    return {"GB/s": rates[best], "variant": best, "bytes_moved": 2 * n * 4,
-            "all_variants_GBs": {k: round(v, 1) for k, v in rates.items()},
-            "method": "read + write of %d MiB -> %d MiB, mean of %d launches each, HIP events; the fastest variant is the ceiling"
-                      % (mbytes, mbytes, reps)}
+def mixed_ceiling(ceil, rd, wr):
+    """GB/s a stream of `rd` read and `wr` written bytes can reach if reads run at the read ceiling and writes at the
+    write ceiling, one after the other (the copy ceiling is that same mix at rd == wr, measured)."""
+    if rd + wr == 0:
+        return None
+    return (rd + wr) / (rd / ceil["read"] + wr / ceil["write"])
+
+
+def library_sha256(lib):
+    import hashlib
+    h = hashlib.sha256()
+    with open(lib.path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def source_sha256():
+    """sha256 over the kernel sources and the C header: ties a measurement to the CODE even where the binary differs
+    by an embedded build path"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "differentiable-point-clouds_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.inc")) +
+                    [os.path.join(csrc, "Makefile"), os.path.join(ROOT, "include", "dpc_hip.h")]):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def pmc_traffic(lib, args, case):
+    """PMC-measured bytes per launch from profiles/traffic.json -- only if they were taken on THIS build of the library
+    (the file carries the sha256 of the libdpc_hip.so it was measured on; scripts/gpu_round4.sh writes both) and on
+    this workload.  Returns (entry | {}, source | None, note | None)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return {}, None, "no profiles/traffic.json"
+    try:
+        doc = json.load(open(tpath))
+    except (ValueError, OSError) as e:
+        return {}, None, "profiles/traffic.json unreadable (%s)" % e
+    default_sigma = {1: 1.0, 2: 1.6, 3: 3.0, 5: 2.0}[args.config]
+    key = "config%d" % args.config + ("" if args.sigma in (None, default_sigma) else "_sigma%g" % args.sigma)
+    if args.k is not None or args.vox is not None or args.num_points is not None or args.points != "shell":
+        return {}, None, "no PMC passes for this workload variant"
+    ent = doc.get(key)
+    if ent is None:
+        return {}, None, "profiles/traffic.json has no entry %r" % key
+    if doc.get("lib_sha256") != library_sha256(lib) and doc.get("src_sha256") != source_sha256():
+        return {}, None, ("profiles/traffic.json was measured on another build of libdpc_hip.so (library sha256 %s..., this one "
+                          "%s...; kernel sources differ too): re-run scripts/gpu_round4.sh"
+                          % (str(doc.get("lib_sha256"))[:12], library_sha256(lib)[:12]))
+    if case["B"] != ent.get("B") or case["N"] != ent.get("N", case["N"]):
+        return {}, None, "profiles/traffic.json entry %r is for another batch / point count" % key
+    return ent, "profiles/traffic.json[%s] (rocprofv3 --pmc passes on this build, see profiles/README.md)" % key, None
 
 
 def self_launch(ngpus, argv):
@@ -264,6 +370,11 @@ def main():
     ap.add_argument("--points", default="shell", choices=["shell", "ball"],
                     help="synthetic cloud: noisy sphere shell (surface-like, default) or uniform ball (SURVEY.md 8(d))")
     ap.add_argument("--num-points", type=int, default=None, help="override N (projector-only workloads)")
+    ap.add_argument("--sigma", type=float, default=None,
+                    help="override the blur's relative sigma (the reference anneals it 3.0 -> 0.2 over a run with K fixed, "
+                         "model_pc.py:33-38; the library runs the tap count the sigma still needs)")
+    ap.add_argument("--k", type=int, default=None, help="override the Gaussian kernel size (projector-only workloads)")
+    ap.add_argument("--vox", type=int, default=None, help="override the grid size vox_size (projector-only workloads)")
     ap.add_argument("--projector-only", action="store_true", help="config 3: time the projector alone at the training shape")
     ap.add_argument("--keep-prob", type=float, default=1.0, help="config 3: point dropout keep probability (N = 8000 * keep)")
     ap.add_argument("--graph", action="store_true",
@@ -337,30 +448,23 @@ def main():
             if hi - lo == 0:
                 raise SystemExit("--scaling strong: %d views do not split over %d ranks" % (total, world))
             batch, args.global_views = hi - lo, total
-        case = build_case(args.config, batch, device, seed_offset=1000 * rank, kind=args.points, N=args.num_points)
+        case = build_case(args.config, batch, device, seed_offset=1000 * rank, kind=args.points, N=args.num_points,
+                          sigma=args.sigma, K=args.k, D=args.vox)
         run = lambda: step(case)
+    numa_note = dd.bind_to_gpu_numa(device) if (world > 1 and not DRY_RUN) else None
     graph_note = None
     if args.graph and train and DRY_RUN:
         args.graph, graph_note = False, "dry run: the recordable reducer (GradBuckets) runs eagerly under gloo"
     if args.graph and train:
-        # The training step is ~280 launches (stock PyTorch layers, fused optimiser, the library's 10 kernels): eager,
+        # The training step is ~250 launches (stock PyTorch layers, fused optimiser, the library's kernels): eager,
         # the host sets the pace.  The whole step -- nets, projector, loss epilogue, backward, (N > 1: the bucketed RCCL
         # all-reduce of the gradients, issued from gradient hooks and overlapped with the backward pass,) Adam -- is
-        # recorded into ONE hipGraph per rank (the library only enqueues on the stream it is handed) and replayed.
-        # capture_error_mode thread_local: the RCCL watchdog thread may query events meanwhile.
+        # recorded into ONE hipGraph per rank and replayed (dpc_amd.graphs.RecordedStep: the shared recipe -- warm-up
+        # count, barrier before the capture, thread-local capture mode, re-record when the blur's tap count moves).
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3 if world == 1 else 11):   # allocator, MIOpen solver search, Adam state, RCCL channels
-                    case["run"]()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            dd.barrier(device)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                case["graph_loss"] = case["run"]()
-            run = graph.replay
+            recorded = dpc_amd.graphs.RecordedStep(case["run"], world=world, device=device,
+                                                   key=case["projector"].effective_tap_counts)
+            run = recorded
         except Exception as e:                       # noqa: BLE001
             # A capture that dies half way leaves the rank's streams in capture mode (seen with gloo on CUDA tensors,
             # whose collectives fork streams that never join: hipErrorStreamCaptureUnjoined) -- there is no clean way on
@@ -374,17 +478,8 @@ def main():
         # per rank and thread-local (an RCCL watchdog thread may touch the runtime meanwhile); if it fails on
         # some runtime the run goes on eagerly and says so in the line.
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    step(case)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                case["graph_grads"] = step(case)
-            run = graph.replay
+            # (no collective inside this step: world = 1 as far as the recording is concerned)
+            run = dpc_amd.graphs.RecordedStep(lambda: step(case), world=1, device=device)
         except Exception as e:                       # noqa: BLE001 -- report, do not lose the measurement
             if explicit_graph:
                 raise
@@ -450,47 +545,64 @@ def main():
         per_step = {k: v[1] / psteps for k, v in agg.items()}
         dom = max(agg, key=lambda k: agg[k][1])
         dom_ms = agg[dom][1] / agg[dom][0]
-        save_xy = lib.saves_xy(case["B"], case["N"], case["D"], case["K"])
-        alg = kernel_algorithmic_bytes(dom, case, save_xy)
-        traffic, tsrc, ent = None, None, {}
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                ent = json.load(open(tpath)).get("config%d" % args.config, {})
-                if ent.get(dom) is not None and case["B"] == ent.get("B") and case["N"] == ent.get("N", case["N"]):
-                    traffic, tsrc = ent[dom], "profiles/traffic.json (rocprofv3 --pmc passes, see profiles/README.md)"
-            except (ValueError, OSError):
-                pass
-        step_bytes = dpc_amd.synthetic.algorithmic_bytes_per_view(case["N"], case["D"], case["D"]) * case["B"]
-        # what THIS implementation has to move per view: splat 1 V (write), collapse 1 V (read; + 1 V when it also
-        # stores G2), collapse VJP 2 V, gather 1 V -- the raw grid and the y/x-blurred gradient grid never exist
-        V = 4 * case["D"] ** 3
-        impl_bytes = step_bytes - (3 if save_xy else 2) * V * case["B"]
-        step_traffic = None
-        if tsrc is not None:
-            step_traffic = ent.get("_step_total")
+        k_run = case["K"]
+        if train:
+            k_run = case["projector"].effective_tap_counts()[2]
+        elif case.get("kern") is not None:
+            k_run = dpc_amd.util.point_cloud.effective_tap_counts(case["cfg"], case["kern"])[2]
+        save_xy = lib.saves_xy(case["B"], case["N"], case["D"], k_run)
+        # the bytes the kernels must move for this run's clouds (projector workloads: occupied planes counted from
+        # the clouds themselves; training step: the dense model, the clouds are the decoder's output)
+        fused_path = dpc_amd.ops.uses_fused_path(lib, case["B"], case["N"], dpc_amd.util.point_cloud._meta(
+            dpc_amd.default_config(vox_size=case["D"])), (k_run,) * 3)
+        occ = None if (train or not fused_path) else plane_occupancy(case)
+        by_kernel = {k: kernel_bytes(k, case, save_xy, occ) for k in per_step}
+        rd, wr = by_kernel[dom]
+        launches_per_step = agg[dom][0] / psteps
+        impl_step = sum(a + b for a, b in by_kernel.values())
+        ent, tsrc, tnote = pmc_traffic(lib, args, case) if not train else ({}, None, "training step: projector traffic not taken")
+        traffic = ent.get(dom)
+        step_traffic = ent.get("_step_total")
         proj_ms = sum(per_step.values()) if train else ms_step     # config 3: the projector's share of the step
-        ceiling = copy_ceiling(lib, device)
-        ach = alg / (dom_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": tsrc, "kernel_ms": dom_ms, "kernel_alg_bytes": alg,
+        ceil = hbm_ceilings(lib, device)
+        ach = (rd + wr) / (dom_ms * 1e-3) / 1e9
+        kceil = mixed_ceiling(ceil, rd, wr)
+        srd, swr = sum(a for a, _ in by_kernel.values()), sum(b for _, b in by_kernel.values())
+        sceil = mixed_ceiling(ceil, srd, swr)
+        V = 4 * case["D"] ** 3
+        model_step = dpc_amd.synthetic.algorithmic_bytes_per_view(case["N"], case["D"], case["D"]) * case["B"]
+        model_kernel = {"zfwd": 1, "zbwd": 2, "splat_xy": 1, "gather_yx": 1}.get(dom)
+        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": tsrc, **({"traffic_note": tnote} if tnote else {}),
                 "measured_achieved": None if traffic is None else traffic / (dom_ms * 1e-3) / 1e9,
-                "copy_ceiling": ceiling, "frac_of_ceiling": ach / ceiling["GB/s"],
+                "kernel_ms": dom_ms, "kernel_launches_per_step": launches_per_step,
+                "kernel_bytes": {"read": rd, "written": wr,
+                                 "basis": ("occupied planes of this run's clouds (%d of %d) + point records + images"
+                                           % (occ[0], case["B"] * case["D"]) if occ else "dense planes + point records + images")},
+                "ceilings": ceil, "kernel_ceiling": kceil, "vs_ceiling": None if not kceil else ach / kceil,
+                "taps_run": k_run, "saves_xy_grid": bool(save_xy),
                 "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items())},
-                "step_alg_bytes": step_bytes, "step_alg_bytes_impl": impl_bytes, "step_measured_bytes": step_traffic,
+                "kernel_bytes_per_step": {k: a + b for k, (a, b) in sorted(by_kernel.items())},
                 "step_ms": proj_ms,
                 "step_scope": ("library kernels only (sum of their HIP-event durations inside the training step)"
                                if train else "whole timed step"),
-                "step_achieved": step_bytes / (proj_ms * 1e-3) / 1e9,
-                "step_frac": step_bytes / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "step_impl_achieved": impl_bytes / (proj_ms * 1e-3) / 1e9,
-                "step_impl_frac": impl_bytes / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "step_impl_frac_of_ceiling": impl_bytes / (proj_ms * 1e-3) / 1e9 / ceiling["GB/s"],
+                "step_bytes": impl_step, "step_achieved": impl_step / (proj_ms * 1e-3) / 1e9,
+                "step_frac": impl_step / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "step_ceiling": sceil, "step_vs_ceiling": None if not sceil else impl_step / (proj_ms * 1e-3) / 1e9 / sceil,
+                "step_measured_bytes": step_traffic,
                 "step_measured_achieved": None if step_traffic is None else step_traffic / (proj_ms * 1e-3) / 1e9,
-                "which_is_which": "frac/step_frac: SURVEY 8(d) byte MODEL over the 8 TB/s spec peak; *_impl: the bytes this "
-                                  "implementation must move; measured_*: PMC bytes (rocprofv3, profiles/traffic.json); "
-                                  "*_of_ceiling: over the float4 copy measured in this run"}
+                "model": {"what": "SURVEY.md 8(d) stage model: 8 V + P bytes per view, each stage touching each dense grid once "
+                                  "-- what an UNFUSED pipeline must move; this one moves 5 V (<= 11 taps) or 6 V and skips "
+                                  "empty planes, so these rates may exceed the peak and are not roofline fractions",
+                          "step_bytes": model_step, "step_rate": model_step / (proj_ms * 1e-3) / 1e9,
+                          "step_rate_over_peak": model_step / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "kernel_bytes": None if model_kernel is None else model_kernel * V * case["B"],
+                          "kernel_rate": None if model_kernel is None else model_kernel * V * case["B"] / (dom_ms * 1e-3) / 1e9},
+                "which_is_which": "achieved / frac / step_*: bytes this implementation must move (kernel_bytes) over HIP-event "
+                                  "time, against the 8 TB/s spec peak; vs_ceiling: against this run's measured read / write "
+                                  "streams mixed like the kernel's bytes; traffic / measured_*: PMC bytes (rocprofv3) of this "
+                                  "very build, else null; model.*: the survey's unfused 8 V model, for reference only"}
 
     if rank == 0:
         global_views = getattr(args, "global_views", None) or world * case["B"]    # (strong scaling: uneven slices add up)
@@ -516,12 +628,15 @@ def main():
             "data": ("dry run on the CPU emulation library: NOT a measurement" if DRY_RUN else
                      "ranks share one GPU (DPC_BENCH_SHARE_GPU): NOT a measurement"
                      if os.environ.get("DPC_BENCH_SHARE_GPU") == "1" else "synthetic"),
-            "config": {"workload": workload, "global_batch": global_views, "K": case["K"],
+            "config": {"workload": workload, "global_batch": global_views, "K": case["K"], "sigma": case["sigma"],
+                       "taps_run": (roof or {}).get("taps_run"),
                        "hip_graph": bool(args.graph), **({"hip_graph_note": graph_note} if graph_note else {}),
                        "burn_in_s": 0.0 if DRY_RUN else args.burn_in,
                        "training_step": bool(train),
-                       "parallelism": ("models sharded x%d (%s), gradient all-reduce over RCCL" % (world, case.get("reducer") or "DDP")) if train else
-                                      ("views sharded x%d, no data-path collective" % world)},
+                       "parallelism": (("models sharded x%d (%s), gradient all-reduce over RCCL" % (world, case.get("reducer") or "DDP")) if train else
+                                       ("views sharded x%d, no data-path collective" % world))
+                                      + ("" if world == 1 else " [%s%s]" % (dd.collective_library() or "no process group",
+                                                                             "; rank 0: " + numa_note if numa_note else ""))},
             "timing": None if not blocks else {
                 "repeats": len(blocks), "steps_per_block": args.steps, "clock": "HIP events, rank 0",
                 "ms_per_step_median": pctl(blocks, 50), "ms_per_step_p10": pctl(blocks, 10),

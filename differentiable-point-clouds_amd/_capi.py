@@ -57,7 +57,10 @@ SIGNATURES = {
     "dpc_profile_count": (ctypes.c_int, []),
     "dpc_profile_get": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
                                        ctypes.POINTER(ctypes.c_float)]),
+    "dpc_compiled_taps": (ctypes.c_int, [ctypes.c_int]),
     "dpc_debug_copy": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, ctypes.c_int]),
+    "dpc_debug_read": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, ctypes.c_int]),
+    "dpc_debug_fill": (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.c_float, ctypes.c_int]),
     "dpc_saved_layout": (ctypes.c_int, [_SP, _PP]),
     "dpc_project_forward": (ctypes.c_int, [_P, _SP, _PP] + [_P] * 8 + [_P] * 8 + [_P, ctypes.c_size_t]),
     "dpc_project_backward": (ctypes.c_int, [_P, _SP, _PP] + [_P] * 8 + [_P] * 6 + [_P] * 3 + [_P] * 5
@@ -113,6 +116,13 @@ class DpcLibrary(object):
 
     def version(self):
         return self.dpc_version().decode()
+
+    def compiled_taps(self, K):
+        """smallest tap count >= K with compile-time-unrolled kernels, 0 if none (cached: sits on the per-step path)"""
+        c = self.__dict__.setdefault("_compiled_taps", {})
+        if K not in c:
+            c[K] = int(self.dpc_compiled_taps(int(K)))
+        return c[K]
 
     def profile(self, on):
         self.check(self.dpc_profile_enable(1 if on else 0), "dpc_profile_enable")

@@ -107,6 +107,12 @@ const char* dpc_version(void) { return "dpc_hip 0.2.0 (gfx950)"; }
 
 size_t dpc_abi_struct_bytes(int which) { return which == 0 ? sizeof(DpcShape) : which == 1 ? sizeof(DpcParams) : 0; }
 
+int dpc_compiled_taps(int K) {
+  for (int k = K < 3 ? 3 : (K | 1); k <= DPC_MAX_TAPS; k += 2)
+    if (tap_compiled(k)) return k;
+  return 0;
+}
+
 int dpc_profile_enable(int on) {
   dpcprof::clear();
   std::lock_guard<std::mutex> lk(dpcprof::g_mu);
@@ -142,6 +148,7 @@ size_t dpc_point_index_ints(const DpcShape* shape) {
   return point_index_ints(*shape);
 }
 
+#define DPC_DEBUG_READ_BLOCKS (256 * 32)
 int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, int width) {
   if (!src || !dst) return DPC_E_NULL;
   if (n == 0 || (n % 4) != 0) return DPC_E_SHAPE;
@@ -172,6 +179,35 @@ int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, 
     return DPC_E_MODE;
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? DPC_OK : (int)e;
+}
+
+int dpc_debug_read(dpc_stream_t stream, const float* src, size_t n, float* partials, int variant) {
+  if (!src || !partials) return DPC_E_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  const int U = (variant % 100) >= 8 ? 8 : 4;
+  const size_t per = (size_t)4 * U * DPC_BLOCK;
+  if (n == 0 || n % per != 0) return DPC_E_SHAPE;
+  size_t blocks = n / per;
+  if (blocks > DPC_DEBUG_READ_BLOCKS) blocks = DPC_DEBUG_READ_BLOCKS;
+  while ((n / per) % blocks != 0) --blocks;
+  const dim3 g((unsigned)blocks, 1, 1), block(DPC_BLOCK, 1, 1);
+  if (variant == 4) DPC_LAUNCH("read4x4", (k_read_sum<4, false>), g, block, 0, st, src, partials, n);
+  else if (variant == 8) DPC_LAUNCH("read4x8", (k_read_sum<8, false>), g, block, 0, st, src, partials, n);
+  else if (variant == 104) DPC_LAUNCH("read4x4nt", (k_read_sum<4, true>), g, block, 0, st, src, partials, n);
+  else if (variant == 108) DPC_LAUNCH("read4x8nt", (k_read_sum<8, true>), g, block, 0, st, src, partials, n);
+  else return DPC_E_MODE;
+  return last_error();
+}
+
+int dpc_debug_fill(dpc_stream_t stream, float* dst, size_t n, float value, int variant) {
+  if (!dst) return DPC_E_NULL;
+  if (n == 0 || (n % 4) != 0) return DPC_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g(256 * 16, 1, 1), block(DPC_BLOCK, 1, 1);
+  if (variant == 0) DPC_LAUNCH("fill4", (k_fill<false>), g, block, 0, st, dst, n, value);
+  else if (variant == 100) DPC_LAUNCH("fill4nt", (k_fill<true>), g, block, 0, st, dst, n, value);
+  else return DPC_E_MODE;
+  return last_error();
 }
 
 int dpc_profile_count(void) {

@@ -39,6 +39,54 @@ def init(backend=None, device=None):
     return rank, world, device
 
 
+def bind_to_gpu_numa(device):
+    """Pin this process to the CPUs of the NUMA node its GPU hangs off (one process per GPU: the launch thread, the
+    RCCL proxy thread and the host staging buffers then stay on the socket next to the device).  The node comes from
+    sysfs (/sys/bus/pci/devices/<bdf>/local_cpulist); anything missing -- no such file, a container without the
+    topology, a platform without sched_setaffinity -- leaves the affinity alone.  Returns a short description for the
+    bench line, or None."""
+    try:
+        if device is None or torch.device(device).type != "cuda":
+            return None
+        pr = torch.cuda.get_device_properties(device)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        base = "/sys/bus/pci/devices/%s/" % bdf
+        with open(base + "local_cpulist") as f:
+            spec = f.read().strip()
+        cpus = set()
+        for part in spec.split(","):
+            if part:
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0)
+        cpus &= allowed
+        if not cpus or cpus == allowed:
+            return None
+        os.sched_setaffinity(0, cpus)
+        node = "?"
+        try:
+            with open(base + "numa_node") as f:
+                node = f.read().strip()
+        except OSError:
+            pass
+        return "GPU %s -> NUMA node %s (%d CPUs)" % (bdf, node, len(cpus))
+    except Exception:  # noqa: BLE001 -- placement only affects speed
+        return None
+
+
+def collective_library():
+    """what the "nccl" backend really is here, for the bench line: RCCL's version and the world size it sees"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    desc = "backend %s, world %d" % (dist.get_backend(), dist.get_world_size())
+    if dist.get_backend() == "nccl":
+        try:
+            desc += ", RCCL %s" % ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            pass
+    return desc
+
+
 def shard_range(total, rank, world):
     """Contiguous, balanced slice [lo, hi) of `total` instances for `rank`."""
     base, rem = divmod(int(total), int(world))

@@ -115,6 +115,7 @@ class ModelPointCloud(object):
         self._params = cfg
         self._global_step = global_step
         self._device = device
+        self._follow_tap_counts = False
         self.setup_sigma()
         self.setup_misc()
 
@@ -130,8 +131,23 @@ class ModelPointCloud(object):
             # a recorded step holds the ADDRESSES of the filter taps: new values go into the same buffers
             for old, new in zip(self._gauss_kernel, kernel):
                 old.copy_(new)
+                # the host-side tag of how many taps matter (gauss_kernel.py) moves with sigma ONLY if the caller has
+                # promised to record the step again when the tap counts change; a graph recorded once keeps running
+                # the kernels (and tap pointers) of its capture, which is only right for the full filter
+                if self._follow_tap_counts and hasattr(new, "dpc_support"):
+                    old.dpc_support = new.dpc_support
+                elif hasattr(old, "dpc_support"):
+                    del old.dpc_support
         else:
             self._gauss_kernel = kernel
+
+    def effective_tap_counts(self):
+        """(Kx, Ky, Kz) the projector runs at the current sigma: the blur's outer taps fall below 1e-8 of the centre
+        tap as sigma is annealed, and the library then runs the kernels of the smaller filter (util.point_cloud.
+        _flat_taps).  A recorded step (HIP graph) holds the kernels of ONE such triple: dpc_amd.graphs.RecordedStep
+        takes this method as its `key` and records the step again when the triple moves."""
+        from .util.point_cloud import effective_tap_counts
+        return effective_tap_counts(self.cfg(), self._gauss_kernel, self._device)
 
     def setup_misc(self, generator=None):                     # model_pc.py:161-168
         """Reference cloud of the pose_student_align_loss: 2000 points ~ N(0,1) clipped to +-3
@@ -146,16 +162,27 @@ class ModelPointCloud(object):
         if getattr(self, "_graph_replay", False):
             self._refresh_dropout_keep()
 
-    def enable_graph_replay(self):
+    def enable_graph_replay(self, follow_tap_counts=False):
         """Make everything that changes from step to step live in device memory at fixed addresses, so that a
         training step recorded ONCE into a HIP graph (torch.cuda.graph) stays right when replayed: the blur taps
         are updated in place by set_global_step, and the fused dropout reads {keep, seed} from a device tensor --
         `keep` follows the schedule through set_global_step (a fill_, enqueued between replays), `seed` is advanced
         by a few integer launches that are part of the recorded step.  Call before capturing; then per step:
-        set_global_step(step); graph.replay()."""
+        set_global_step(step); graph.replay().
+
+        follow_tap_counts: a recorded step runs the blur kernels of ONE tap count.  False (default): the full filter
+        (cfg.pc_gauss_kernel_size taps) for the whole run, whatever sigma does -- one graph stays valid.  True: the
+        filter is trimmed to the taps the current sigma still needs (util.point_cloud._flat_taps) and the CALLER
+        records the step again whenever effective_tap_counts() changes -- dpc_amd.graphs.RecordedStep(run,
+        key=projector.effective_tap_counts) does exactly that."""
         if self._device is None or torch.device(self._device).type != "cuda":
             raise ValueError("graph replay needs the projector on a ROCm device")
         self._graph_replay = True
+        self._follow_tap_counts = bool(follow_tap_counts)
+        if not self._follow_tap_counts:
+            for k in self._gauss_kernel:
+                if hasattr(k, "dpc_support"):
+                    del k.dpc_support
         seed = ((torch.initial_seed() ^ self._rank_salt()) * 1103515245 + 12345) & 0x7fffffff
         self._dropout_seed64 = torch.tensor([seed], dtype=torch.int64, device=self._device)
         self._dropout_state = torch.zeros(2, dtype=torch.int32, device=self._device)

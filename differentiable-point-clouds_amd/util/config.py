@@ -41,7 +41,7 @@ class Config(dict):
         pc_gauss_filter_gt_switch_off=False, proj_rgb_weight=0.0, max_dataset_depth=10.0,
         proj_weight=1.0, drc_weight=0.0, proj_depth_weight=0.0,
         # (this build, not reference keys) in-kernel point dropout / replication over views and candidates
-        pc_fused_dropout=True, pc_replicate_in_kernel=True, pc_fused_proj_loss=True,
+        pc_fused_dropout=True, pc_replicate_in_kernel=True, pc_fused_proj_loss=True, pc_trim_gauss_taps=True,
     )
 
     def __init__(self, **kw):

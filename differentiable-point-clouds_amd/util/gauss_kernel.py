@@ -15,6 +15,30 @@ def _device(device):
     return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
 
 
+# Taps below this fraction of the centre tap are not applied (see effective_half_width).  1e-8 is under the fp32
+# rounding of the sums the taps enter (2^-24 = 6e-8 relative): the trimmed filter's output equals the full one's to
+# fp32 accuracy, while the reference's sigma schedule (3.0 -> 0.2 with K = 21 fixed, dpc/models/model_pc.py:33-38,
+# default_config.yaml:49-50) spends half of a run at sigmas whose outer taps are that small.
+TAP_DROP_REL = 1e-8
+
+
+def effective_half_width(sig, half):
+    """Largest offset m <= half whose tap exp(-m^2 / 2 sig^2) is still >= TAP_DROP_REL of the centre tap: the filter
+    of 2 * half + 1 taps acts as one of 2 * m + 1 (the normalisation still runs over all the taps, as in the reference,
+    so the kept taps are bit-identical to the full filter's)."""
+    sig = float(sig)
+    if not (sig > 0.0) or not math.isfinite(sig):
+        return int(half)
+    return int(min(half, math.floor(sig * math.sqrt(-2.0 * math.log(TAP_DROP_REL)))))
+
+
+def _tag_support(t, h):
+    """remember, on the host, how many of the filter's taps matter (read by util.point_cloud._flat_taps; tensors
+    that do not carry the tag -- anything not made here from a host-side sigma -- are applied in full)"""
+    t.dpc_support = int(h)
+    return t
+
+
 def gauss_kernel_1d(l, sig, device=None):
     """Gaussian taps at integer offsets range(-l//2+1., l//2+1.), sum 1, fp32."""
     l = int(l)
@@ -23,9 +47,13 @@ def gauss_kernel_1d(l, sig, device=None):
                          "asymmetric for them and the reference only uses odd sizes")
     dev = sig.device if (isinstance(sig, torch.Tensor) and device is None) else _device(device)
     xx = torch.arange(-l // 2 + 1.0, l // 2 + 1.0, dtype=torch.float32, device=dev)
+    host_sigma = None if isinstance(sig, torch.Tensor) else float(sig)
     sig = torch.as_tensor(sig, dtype=torch.float32, device=dev)
     kernel = torch.exp(-xx ** 2 / (2.0 * sig ** 2))
-    return kernel / kernel.sum()
+    kernel = kernel / kernel.sum()
+    if host_sigma is not None:
+        _tag_support(kernel, effective_half_width(host_sigma, l // 2))
+    return kernel
 
 
 def gauss_smoothen_image(cfg, img, sigma_rel):
@@ -40,10 +68,18 @@ def gauss_smoothen_image(cfg, img, sigma_rel):
     return x.permute(0, 2, 3, 1)
 
 
+def _filters(kernel_1d, shapes):
+    out = [kernel_1d.reshape(*s) for s in shapes]
+    h = getattr(kernel_1d, "dpc_support", None)
+    if h is not None:
+        for f in out:
+            _tag_support(f, h)
+    return out
+
+
 def separable_kernels(kernel):
     size = kernel.shape[0]
-    return [kernel.reshape(1, 1, size, 1, 1), kernel.reshape(1, size, 1, 1, 1),
-            kernel.reshape(size, 1, 1, 1, 1)]
+    return _filters(kernel, [(1, 1, size, 1, 1), (1, size, 1, 1, 1), (size, 1, 1, 1, 1)])
 
 
 def smoothing_kernel(cfg, sigma, device=None):
@@ -57,8 +93,7 @@ def smoothing_kernel(cfg, sigma, device=None):
         if fsz_z % 2 == 0:
             fsz_z += 1
         kernel_1d_z = gauss_kernel_1d(fsz_z, sigma * ratio, device)
-        return [kernel_1d.reshape(1, 1, fsz, 1, 1), kernel_1d.reshape(1, fsz, 1, 1, 1),
-                kernel_1d_z.reshape(fsz_z, 1, 1, 1, 1)]
+        return _filters(kernel_1d, [(1, 1, fsz, 1, 1), (1, fsz, 1, 1, 1)]) + _filters(kernel_1d_z, [(fsz_z, 1, 1, 1, 1)])
     if not cfg.pc_separable_gauss_filter:
         raise NotImplementedError("dense 3-D Gaussian kernel (pc_separable_gauss_filter=false)")
     return separable_kernels(kernel_1d)

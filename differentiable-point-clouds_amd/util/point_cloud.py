@@ -43,7 +43,14 @@ def _meta(cfg, collapse=None):
 def _flat_taps(cfg, kernel, device):
     """Reference kernels are a list of 3 conv3d filters [1,1,K,1,1], [1,K,1,1,1],
     [Kz,1,1,1,1] applied in list order; which axis each one blurs is read off
-    its shape (dpc/util/gauss_kernel.py:27-32)."""
+    its shape (dpc/util/gauss_kernel.py:27-32).
+
+    Filters made by ``smoothing_kernel`` from a host-side sigma carry ``dpc_support`` = the largest tap offset whose
+    weight is still >= 1e-8 of the centre tap (util/gauss_kernel.py).  Of such a filter only the central taps are
+    handed to the kernels -- as a view into the same buffer, rounded up to the next tap count the library has
+    compiled kernels for (dpc_compiled_taps) -- so that a K = 21 configuration whose sigma has been annealed to 0.8
+    runs the 11-tap kernels (and their cheaper saved-state layout) instead of multiplying by twenty zeros.  Results
+    equal the full filter's to fp32 rounding; ``cfg.pc_trim_gauss_taps = False`` switches it off."""
     if kernel is None:
         return None, None, None
     if not cfg.pc_separable_gauss_filter or isinstance(kernel, torch.Tensor):
@@ -52,16 +59,51 @@ def _flat_taps(cfg, kernel, device):
     # projector runs every step: remember the flattened taps of the last filter list seen
     if not all(isinstance(k, torch.Tensor) for k in kernel):
         return _flat_taps_uncached(kernel, device)
-    key = tuple((id(k), k._version) for k in kernel) + (str(device),)      # _version: in-place edits invalidate
+    trim = bool(getattr(cfg, "pc_trim_gauss_taps", True))
+    # _version: in-place edits invalidate; dpc_support: the host-side tag moves with sigma (also in place under graph replay)
+    key = tuple((id(k), k._version, getattr(k, "dpc_support", None)) for k in kernel) + (str(device), trim)
     hit = _TAPS_CACHE.get("key")
     if hit == key and all(a is b for a, b in zip(_TAPS_CACHE["filters"], kernel)):
         return _TAPS_CACHE["taps"]
     out = _flat_taps_uncached(kernel, device)
+    if trim:
+        out = _trim_taps(kernel, out)
     _TAPS_CACHE.update(key=key, filters=list(kernel), taps=out)
     return out
 
 
 _TAPS_CACHE = {}
+
+
+def _trim_taps(kernel, taps):
+    """central slices (views) of the flattened taps, per axis, for filters tagged with their effective support"""
+    support = {}
+    for k in kernel:
+        h = getattr(k, "dpc_support", None)
+        if h is not None:
+            kd, kh = int(k.shape[0]), int(k.shape[1])
+            support["z" if kd > 1 else ("y" if kh > 1 else "x")] = int(h)
+    lib = _capi.get_library()
+    out = []
+    for axis, t in zip("xyz", taps):
+        h = support.get(axis)
+        if t is not None and h is not None:
+            full = int(t.numel())
+            k_eff = lib.compiled_taps(2 * max(h, 1) + 1)
+            if 0 < k_eff < full:
+                off = (full - k_eff) // 2
+                t = t[off:off + k_eff]
+        out.append(t)
+    return tuple(out)
+
+
+def effective_tap_counts(cfg, kernel, device=None):
+    """(Kx, Ky, Kz) the projector will run for this filter list (0 = axis not blurred): what a caller that replays a
+    recorded step has to watch -- a HIP graph holds the kernels of ONE set of tap counts (dpc_amd.graphs.RecordedStep)."""
+    if kernel is None:
+        return (0, 0, 0)
+    dev = device if device is not None else kernel[0].device
+    return tuple(0 if t is None else int(t.numel()) for t in _flat_taps(cfg, kernel, dev))
 
 
 def _flat_taps_uncached(kernel, device):

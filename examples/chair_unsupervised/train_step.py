@@ -113,20 +113,11 @@ def main():
     inputs = synthetic_batch(cfg, device, args.image_size, seed=rank)
     run = lambda: train_step(model, projector, inputs, opt, world, buckets=buckets)
     if args.graph:
-        projector.enable_graph_replay()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):                   # allocator, MIOpen solver search, Adam state
-                run()
-        torch.cuda.current_stream().wait_stream(side)
-        graph, static = torch.cuda.CUDAGraph(), {}
-        with torch.cuda.graph(graph):
-            static["loss"] = run()
-
-        def run():
-            graph.replay()
-            return static["loss"]
+        # the shared recipe (dpc_amd/graphs.py): eager warm-up steps (11 with several ranks: RCCL sets its channels up
+        # over the first collectives), barrier, thread-local capture (the RCCL watchdog polls events meanwhile), and a
+        # new recording whenever the annealed blur moves on to a smaller tap count
+        projector.enable_graph_replay(follow_tap_counts=True)
+        run = dpc_amd.graphs.RecordedStep(run, world=world, device=device, key=projector.effective_tap_counts)
     step = 0
     for _ in range(args.warmup):
         projector.set_global_step(step)          # sigma / dropout schedules (in place under --graph)
@@ -150,6 +141,9 @@ def main():
                                      "pose_candidates": cfg.pose_predict_num_candidates, "vox_size": cfg.vox_size,
                                      "K": cfg.pc_gauss_kernel_size, "points": int(cfg.pc_num_points * args.keep_prob),
                                      "params": nparams, "loss": float(loss), "hip_graph": bool(args.graph),
+                                     "graph_recordings": getattr(run, "records", 0),
+                                     "taps_at_end": list(projector.effective_tap_counts()),
+                                     "collectives": dd.collective_library(),
                                      "scheduled": bool(args.scheduled)}}))
     dd.finalize()
 

@@ -110,6 +110,14 @@ const char* dpc_version(void);
  * of discovering a stale mirror through wrong results. */
 size_t dpc_abi_struct_bytes(int which);
 
+/* Smallest Gaussian tap count >= K for which the library holds kernels unrolled at compile time (odd counts 3 .. 21:
+ * the reference's configurations use 11 and 21, default_config.yaml:55 / experiments/<name>/config.yaml; the counts in
+ * between serve filters whose outer taps have decayed to nothing under the sigma schedule of
+ * dpc/models/model_pc.py:33-38), or 0 when there is none -- such a filter runs through the run-time-K kernels of the
+ * generic path.  A caller that knows that only the central K' taps of its K-tap filter matter may pass the slice
+ * taps + (K - K') / 2 with tap count K' = dpc_compiled_taps(K'_needed): the taps are a plain array. */
+int dpc_compiled_taps(int K);
+
 /* Optional per-kernel timing for benchmarking: while enabled, every kernel /
  * memset the library enqueues is bracketed by HIP events recorded on the launch
  * stream.  dpc_profile_get synchronises on record i and returns its label
@@ -126,6 +134,12 @@ int dpc_profile_get(int i, const char** label, float* ms);
  * nontemporal policy (n a multiple of 4096 * that count) -- the variants bench.py takes its
  * on-box copy ceiling from. */
 int dpc_debug_copy(dpc_stream_t stream, const float* src, float* dst, size_t n, int width);
+/* Diagnostics, the one-directional companions of dpc_debug_copy (bench.py's read / write ceilings): a pure reader
+ * (float4 loads, `variant` 4 | 8 in flight per lane, +100 = nontemporal; the per-work-group sums land in `partials`,
+ * which must hold 8192 floats; n a multiple of 4096 * that count) and a pure writer (float4 stores of `value`;
+ * variant 0, or 100 = nontemporal; n % 4 == 0). */
+int dpc_debug_read(dpc_stream_t stream, const float* src, size_t n, float* partials, int variant);
+int dpc_debug_fill(dpc_stream_t stream, float* dst, size_t n, float value, int variant);
 
 /* Which clip-gradient record dpc_project_forward leaves for the backward, for
  * this shape: bit 0 (value 1) = grid_raw, the dense pre-clip scatter [B,Dz,D,D]

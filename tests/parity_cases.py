@@ -101,6 +101,15 @@ FUSED_CASES_GPU = FUSED_CASES + [
     (2, 6000, 32, 32, 21, 3.0, False, False),    # D = 32 (2 floats per lane), 21 taps: halo from 5 lanes away
     (2, 8000, 64, 64, 11, 1.6, True, True),      # D = 64, 11 taps, with translation and focal length
     (1, 8000, 64, 64, 5, 0.9, False, False),     # D = 64, 5 taps
+    # round 4: the tap counts that gained compiled kernels (what the annealed sigma trims a 21-tap filter to)
+    (2, 600, 64, 64, 3, 0.6, False, False),
+    (2, 500, 32, 32, 7, 1.2, True, False),
+    (2, 700, 64, 64, 9, 1.5, False, True),
+    (1, 3000, 128, 128, 13, 2.2, False, False),
+    (2, 8000, 64, 64, 15, 2.5, False, False),    # dense gather flow at 15 taps
+    (1, 4000, 64, 64, 17, 2.9, False, False),
+    (1, 1500, 128, 128, 19, 3.2, False, False),
+    (1, 1200, 128, 64, 19, 3.2, False, False),   # vox_size_z = 64 at 128: Kz = 9
 ]
 DENSE_GATHER_CASE_EMU = (1, 3000, 32, 32, 5, 0.8, False, False)    # ~150+ points per occupied plane at D = 32
 

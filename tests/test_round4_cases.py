@@ -1,0 +1,221 @@
+"""Round-4 additions to the CPU tier: the sigma-aware effective tap count (host logic + the emulated kernels of every
+compiled tap count), the dict conversions of the lazily built output dicts, the slow projector under point dropout,
+and the GradBuckets invariants."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import synth
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# effective tap count (dpc/models/model_pc.py:33-38,146-153: sigma is annealed 3.0 -> 0.2 while K stays 21)
+# ---------------------------------------------------------------------------------------------------------------
+def test_effective_half_width_matches_the_taps():
+    """effective_half_width(sigma, h) is the largest offset whose tap is >= 1e-8 of the centre tap, computed from the
+    taps themselves in float64 here."""
+    from dpc_amd.util import gauss_kernel as gk
+    for sigma in (3.0, 2.0, 1.65, 1.64, 1.2, 0.99, 0.98, 0.83, 0.82, 0.5, 0.33, 0.2):
+        for half in (10, 5, 2):
+            m = np.arange(0, half + 1, dtype=np.float64)
+            rel = np.exp(-m * m / (2.0 * sigma * sigma))
+            want = int(np.nonzero(rel >= gk.TAP_DROP_REL)[0].max())
+            assert gk.effective_half_width(sigma, half) == want, (sigma, half)
+    assert gk.effective_half_width(float("nan"), 10) == 10 and gk.effective_half_width(0.0, 10) == 10
+
+
+def test_filters_carry_their_support_and_trim_to_compiled_counts():
+    import dpc_amd
+    from dpc_amd.util import point_cloud as pcu
+    cfg = dpc_amd.default_config(vox_size=64, pc_gauss_kernel_size=21)
+    expect = {3.0: 21, 1.7: 21, 1.6: 19, 1.4: 17, 1.2: 15, 1.0: 13, 0.9: 11, 0.7: 9, 0.5: 7, 0.4: 5, 0.2: 3}
+    for sigma, k_eff in expect.items():
+        kern = dpc_amd.smoothing_kernel(cfg, sigma, device="cpu")
+        assert all(hasattr(k, "dpc_support") for k in kern)
+        tx, ty, tz = pcu._flat_taps(cfg, kern, torch.device("cpu"))
+        assert (tx.numel(), ty.numel(), tz.numel()) == (k_eff,) * 3, (sigma, tx.numel())
+        assert pcu.effective_tap_counts(cfg, kern) == (k_eff,) * 3
+        full = kern[0].reshape(-1)
+        off = (21 - k_eff) // 2
+        # the kept taps are the full filter's own values (a view into its buffer), not a renormalised filter
+        assert tx.data_ptr() == full.data_ptr() + 4 * off
+        assert torch.equal(tx, full[off:off + k_eff])
+        dropped = float(full.sum() - tx.sum())
+        assert dropped <= 21 * 1e-8, (sigma, dropped)
+    cfg_off = dpc_amd.default_config(vox_size=64, pc_gauss_kernel_size=21, pc_trim_gauss_taps=False)
+    kern = dpc_amd.smoothing_kernel(cfg_off, 0.5, device="cpu")
+    assert pcu._flat_taps(cfg_off, kern, torch.device("cpu"))[0].numel() == 21
+    # a filter that does not come from a host-side sigma is applied in full
+    raw = [k.clone() for k in dpc_amd.smoothing_kernel(cfg, 0.5, device="cpu")]
+    assert pcu._flat_taps(cfg, raw, torch.device("cpu"))[0].numel() == 21
+    # vox_size_z: the z filter has its own size and sigma (gauss_kernel.py:38-50)
+    cfgz = dpc_amd.default_config(vox_size=64, vox_size_z=32, pc_gauss_kernel_size=21)
+    kz = dpc_amd.smoothing_kernel(cfgz, 1.2, device="cpu")
+    assert pcu.effective_tap_counts(cfgz, kz) == (15, 15, 7)        # 11 z taps at sigma 0.6: offsets <= 3 matter
+
+
+def test_model_tap_counts_follow_the_sigma_schedule():
+    """ModelPointCloud.effective_tap_counts over the reference's schedule (sigma 3.0 -> 0.2, K = 21): non-increasing,
+    21 for the first ~48 % of the run, <= 11 (the cheaper saved-state layout) for the last ~28 %."""
+    import dpc_amd
+    cfg = dpc_amd.default_config(vox_size=64, pc_gauss_kernel_size=21, pc_relative_sigma=3.0, pc_relative_sigma_end=0.2,
+                                 max_number_of_steps=1000)
+    m = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device="cpu")
+    ks = []
+    for step in range(0, 1001, 10):
+        m.set_global_step(step)
+        k = m.effective_tap_counts()
+        assert k[0] == k[1] == k[2]
+        ks.append(k[0])
+    assert ks[0] == 21 and ks[-1] == 3 and all(a >= b for a, b in zip(ks, ks[1:]))
+    assert abs(sum(k == 21 for k in ks) / len(ks) - 0.483) < 0.02
+    assert abs(sum(k <= 11 for k in ks) / len(ks) - 0.282) < 0.02
+    assert sorted(set(ks)) == [3, 5, 7, 9, 11, 13, 15, 17, 19, 21]
+
+
+@pytest.mark.parametrize("sigma", [1.5, 1.2, 0.8, 0.6, 0.3])
+def test_emu_trimmed_filter_equals_the_full_one(emu, sigma):
+    """The projector with the trimmed filter (19 / 15 / 9 / 7 / 3 taps of a K = 21 configuration, each a different
+    compiled kernel set and, at <= 11 taps, the xy-saving state layout) against the full 21 taps: images to 2e-7,
+    gradients to 2e-6 of their largest entry."""
+    import dpc_amd
+    B, N, D = 2, 300, 32
+    inp = synth.make_inputs(B, N, 11)
+    res = {}
+    for trim in (True, False):
+        cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=21, pc_trim_gauss_taps=trim)
+        kern = dpc_amd.smoothing_kernel(cfg, sigma, device="cpu")
+        t = lambda a: torch.tensor(a, requires_grad=True)
+        pc, pose, scale = t(inp["pc"]), t(inp["pose"]), t(inp["scale"])
+        out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale)
+        w = torch.tensor(np.random.default_rng(5).standard_normal((B, D, D, 1)).astype(np.float32))
+        wd = torch.tensor(np.random.default_rng(6).standard_normal((B, D, D, 1)).astype(np.float32)) * 0.1
+        g = torch.autograd.grad([out["proj"], out["proj_depth"]], [pc, pose, scale], [w, wd])
+        res[trim] = (out["proj"].detach(), out["proj_depth"].detach(), g)
+    a, b = res[True], res[False]
+    assert float((a[0] - b[0]).abs().max()) <= 2e-7
+    assert float((a[1] - b[1]).abs().max()) <= 2e-6
+    for x, y in zip(a[2], b[2]):
+        assert float((x - y).abs().max()) <= 2e-6 * max(1.0, float(y.abs().max())), sigma
+
+
+@pytest.mark.parametrize("K", [3, 7, 9, 13, 15, 17, 19])
+def test_emu_new_tap_counts_match_the_numpy_oracle(emu, K):
+    """Every tap count that gained compiled kernels this round (fused front / back end and z kernels), forward and
+    backward against the float64 NumPy oracle."""
+    import dpc_amd
+    from oracle import dpc_oracle_np as onp
+    B, N, D, sigma = 2, 200, 32, 0.35 * K / 2
+    inp = synth.make_inputs(B, N, 100 + K)
+    cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K, pc_trim_gauss_taps=False)
+    kern = dpc_amd.smoothing_kernel(cfg, sigma, device="cpu")
+    t = lambda a: torch.tensor(a, requires_grad=True)
+    pc, pose, scale = t(inp["pc"]), t(inp["pose"]), t(inp["scale"])
+    out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale)
+    assert dpc_amd.ops.uses_fused_path(dpc_amd.get_library(), B, N, dpc_amd.util.point_cloud._meta(cfg), (K, K, K))
+    gt = torch.tensor(synth.disk_gt(B, D))
+    dproj = ((out["proj"] - gt) / B).detach()
+    g = torch.autograd.grad(out["proj"], [pc, pose, scale], dproj)
+    f64 = lambda x: x.astype(np.float64)
+    taps = onp.smoothing_taps(D, -1, K, sigma)
+    fw = onp.project_forward(f64(inp["pc"]), f64(inp["pose"]), None, f64(inp["scale"]), None, taps, Dz=D, D=D)
+    bw = onp.project_backward(f64(inp["pc"]), f64(inp["pose"]), None, f64(inp["scale"]), None, taps, fw,
+                              dproj=f64(dproj.numpy()))
+    assert np.abs(out["proj"].detach().numpy() - fw["proj"]).max() <= 2e-5
+    for got, key in zip(g, ("dpc", "dpose", "dscale")):
+        ref = bw[key].reshape(got.shape)
+        assert np.abs(got.numpy() - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-12), (K, key)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ADVICE (round 3)
+# ---------------------------------------------------------------------------------------------------------------
+def test_lazy_dicts_convert_with_their_real_entries():
+    import dpc_amd
+    base = {"points_1": torch.arange(12.0).reshape(2, 2, 3)}
+    for conv in (dict, lambda d: {**d}, lambda d: d.copy(), lambda d: dict(d.items())):
+        out = dpc_amd.model_pc.ReplicatedOutputs(base, 3)
+        assert out.points_replication() is not None                      # nothing built yet
+        got = conv(out)
+        assert got["all_points"] is not None and got["all_points"].shape == (6, 2, 3)
+    out = dpc_amd.model_pc.ReplicatedOutputs(base, 3)
+    assert out.pop("all_points").shape == (6, 2, 3) and "all_points" not in out
+    import pickle
+    out = dpc_amd.model_pc.ReplicatedOutputs(base, 2)
+    back = pickle.loads(pickle.dumps(dict(out)))
+    assert back["all_points"].shape == (4, 2, 3)
+    from dpc_amd.util.point_cloud import ProjectionOutputs
+    po = ProjectionOutputs({"proj": 1}, lambda: "V", lambda: "P")
+    assert dict(po) == {"proj": 1, "voxels": "V", "drc_probs": "P"}
+    po = ProjectionOutputs({"proj": 1}, lambda: "V", lambda: "P")
+    assert {**po}["voxels"] == "V" and po.copy()["drc_probs"] == "P"
+
+
+def test_emu_slow_projector_sees_the_dropped_out_cloud(emu):
+    """compute_projection with pc_fast=False and pc_point_dropout != 1 projects int(N * keep) points
+    (dpc/models/model_pc.py:233-251), not the full cloud."""
+    import dpc_amd
+    cfg = dpc_amd.default_config(vox_size=16, pc_num_points=40, predict_pose=True, pose_predict_num_candidates=1,
+                                 step_size=1, batch_size=2, pc_point_dropout=0.25, pc_fast=False)
+    m = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device="cpu")
+    inp = synth.make_inputs(2, 40, 3)
+    seen = {}
+    orig = dpc_amd.model_pc.pointcloud_project
+
+    def spy(cfg_, pts, pose, sigma):
+        seen["n"] = pts.shape[1]
+        return orig(cfg_, pts, pose, sigma)
+
+    dpc_amd.model_pc.pointcloud_project = spy
+    try:
+        outputs = {"points_1": torch.tensor(0.4 * inp["pc"]), "poses": torch.tensor(inp["pose"]),
+                   "scaling_factor": torch.tensor(inp["scale"]), "rgb_1": None}
+        outputs = m.replicate_outputs(outputs)
+        m.compute_projection({}, outputs, is_training=True)
+    finally:
+        dpc_amd.model_pc.pointcloud_project = orig
+    assert seen["n"] == int(40 * 0.25)
+    assert outputs["projs"].shape == (2, 16, 16, 1)
+
+
+def test_grad_buckets_refuse_broken_invariants():
+    import dpc_amd
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    buckets = dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=1)
+    x = torch.randn(5, 4)
+    net(x).sum().backward()
+    buckets.finish()
+    buckets.zero_()
+    # a second backward before finish(): the bucket's all-reduce has already gone out
+    net(x).sum().backward()
+    with pytest.raises(RuntimeError, match="second gradient"):
+        net(x).sum().backward()
+    buckets._arm()
+    buckets.zero_()
+    # optimizer.zero_grad() (set_to_none=True): the views are gone
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    opt.zero_grad()
+    net(x).sum().backward()
+    with pytest.raises(RuntimeError, match="no longer its bucket view"):
+        buckets.finish()
+
+
+def test_grad_buckets_issue_in_bucket_order():
+    """buckets complete in any order, the all-reduces go out in bucket order (what keeps ranks with different
+    completion orders matched)"""
+    import dpc_amd
+    ps = [torch.nn.Parameter(torch.zeros(300000)) for _ in range(3)]          # 1.2 MB each: one bucket per parameter
+    b = dpc_amd.distributed.GradBuckets(ps, bucket_mb=1)
+    assert len(b.buckets) == 3
+    order = [b._of[p] for p in ps]                 # reverse parameter order: [2, 1, 0]
+    assert order == [2, 1, 0]
+    b._hook(ps[0])                                 # bucket 2 completes first: must wait for buckets 0 and 1
+    assert b._next == 0
+    b._hook(ps[2])                                 # bucket 0
+    assert b._next == 1
+    b._hook(ps[1])                                 # bucket 1 -> 1 and 2 go out
+    assert b._next == 3
+    b.finish()
+    assert b._next == 0
