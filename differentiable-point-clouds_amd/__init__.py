@@ -6,7 +6,7 @@ The directory name is not a Python identifier; import it through the
 ``dpc_amd`` alias module at the repo root (``import dpc_amd``) or with
 ``importlib.import_module("differentiable-point-clouds_amd")``.
 """
-from . import _capi, distributed, graphs, model_pc, ops, synthetic, util  # noqa: F401
+from . import _capi, _ext, distributed, graphs, model_pc, ops, synthetic, util  # noqa: F401
 from ._capi import DpcError, get_library  # noqa: F401
 from .util.config import Config, default_config  # noqa: F401
 from .util.drc import drc_depth_projection, drc_event_probabilities, drc_projection  # noqa: F401

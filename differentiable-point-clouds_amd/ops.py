@@ -10,7 +10,7 @@ import os
 
 import torch
 
-from . import _capi
+from . import _capi, _ext
 from ._capi import DpcParams, DpcShape
 
 ProjMeta = collections.namedtuple(
@@ -381,6 +381,32 @@ class ProjectFused(torch.autograd.Function):
         if dfocal is not None:
             dfocal = dfocal.reshape(ctx.focal_shape)
         return dpc, dpose, dtrans, dscale, dfocal, None, None, None, None
+
+
+def project_fused(pc, pose, trans, scale, focal, tx, ty, tz, meta):
+    """pointcloud_project_fast as ONE autograd node -> (proj, proj_depth | None, tr_pc, l2_grad | None, sil_loss | None,
+    sil_winners | None, sil_inst_err | None): through the compiled binding (csrc/dpc_torch.cpp: the same checks, plan,
+    allocations and C-ABI calls as ProjectFused below, in C++) when it is built, through ctypes (ProjectFused) otherwise.
+    Both drive the same library; DPC_BINDING=ctypes forces the second."""
+    ext = _ext.module()
+    if ext is None:
+        return ProjectFused.apply(pc, pose, trans, scale, focal, tx, ty, tz, meta)
+    lib = _capi.get_library()
+    lib_id = lib.__dict__.get("_ext_id")
+    if lib_id is None:
+        lib_id = lib.__dict__["_ext_id"] = ext.open_library(lib.path, lib.host_memory)
+    try:
+        out = ext.project_fused(pc, pose, trans, scale, focal, tx, ty, tz, meta.dropout_state, meta.l2_target, meta.sil_gt,
+                                meta.sil_valid, lib_id, meta.Dz, meta.D, meta.camera_distance, meta.focal_length, meta.eps,
+                                meta.max_depth, bool(meta.pose_quaternion), meta.collapse_mode, meta.dropout_keep,
+                                meta.dropout_seed & 0xffffffff, meta.l2_weight, meta.views_per_cloud or 0, meta.sil_C or 1, _POISON)
+    except RuntimeError as e:
+        msg = str(e)
+        if msg.startswith("DPC_RC:"):           # a status code of the C ABI: raise what the ctypes binding raises
+            _, rc, what = msg.split("\n", 1)[0].split(":", 2)
+            lib.check(int(rc), what.strip())
+        raise
+    return tuple(out)
 
 
 # ---------------------------------------------------------------------------

@@ -60,6 +60,32 @@ class Config(dict):
     def __setattr__(self, k, v):
         self[k] = v
 
+    # every mutation bumps a counter, so that per-step callers (util.point_cloud._meta) can reuse what they derived from
+    # the config instead of re-reading a dozen keys per projector call
+    def __setitem__(self, k, v):
+        dict.__setitem__(self, k, v)
+        self.__dict__["_edits"] = self.__dict__.get("_edits", 0) + 1
+
+    def update(self, *a, **kw):
+        dict.update(self, *a, **kw)
+        self.__dict__["_edits"] = self.__dict__.get("_edits", 0) + 1
+
+    def __delitem__(self, k):
+        dict.__delitem__(self, k)
+        self.__dict__["_edits"] = self.__dict__.get("_edits", 0) + 1
+
+    def pop(self, *a):
+        self.__dict__["_edits"] = self.__dict__.get("_edits", 0) + 1
+        return dict.pop(self, *a)
+
+    def setdefault(self, k, d=None):
+        self.__dict__["_edits"] = self.__dict__.get("_edits", 0) + 1
+        return dict.setdefault(self, k, d)
+
+    def clear(self):
+        self.__dict__["_edits"] = self.__dict__.get("_edits", 0) + 1
+        dict.clear(self)
+
 
 def default_config(**kw):
     return Config(**kw)

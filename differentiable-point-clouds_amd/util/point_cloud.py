@@ -34,10 +34,26 @@ def _dims(cfg):
 
 
 def _meta(cfg, collapse=None):
+    # (a dpc_amd Config counts its edits: the derived tuple is reused until the config changes; any other mapping --
+    # the reference's EasyDict -- is read afresh)
+    edits = cfg.__dict__.get("_edits") if isinstance(cfg, dict) and hasattr(cfg, "__dict__") else None
+    if edits is not None and collapse is None:
+        hit = _META_CACHE.get(id(cfg))
+        if hit is not None and hit[0] == edits and hit[1] is cfg:
+            return hit[2]
     Dz, D = _dims(cfg)
-    if collapse is None:
-        collapse = _capi.DPC_COLLAPSE_MAX if cfg.ptn_max_projection else _capi.DPC_COLLAPSE_DRC
-    return _drc._meta(cfg, Dz, D, collapse)
+    c = collapse
+    if c is None:
+        c = _capi.DPC_COLLAPSE_MAX if cfg.ptn_max_projection else _capi.DPC_COLLAPSE_DRC
+    meta = _drc._meta(cfg, Dz, D, c)
+    if edits is not None and collapse is None:
+        if len(_META_CACHE) > 64:
+            _META_CACHE.clear()
+        _META_CACHE[id(cfg)] = (edits, cfg, meta)
+    return meta
+
+
+_META_CACHE = {}
 
 
 def _flat_taps(cfg, kernel, device):
@@ -61,10 +77,15 @@ def _flat_taps(cfg, kernel, device):
         return _flat_taps_uncached(kernel, device)
     trim = bool(getattr(cfg, "pc_trim_gauss_taps", True))
     # _version: in-place edits invalidate; dpc_support: the host-side tag moves with sigma (also in place under graph replay)
-    key = tuple((id(k), k._version, getattr(k, "dpc_support", None)) for k in kernel) + (str(device), trim)
+    key = [trim, device]
+    for k in kernel:
+        key.append(k._version)
+        key.append(getattr(k, "dpc_support", None))
     hit = _TAPS_CACHE.get("key")
-    if hit == key and all(a is b for a, b in zip(_TAPS_CACHE["filters"], kernel)):
-        return _TAPS_CACHE["taps"]
+    if hit == key:
+        filters = _TAPS_CACHE["filters"]
+        if len(filters) == len(kernel) and all(a is b for a, b in zip(filters, kernel)):
+            return _TAPS_CACHE["taps"]
     out = _flat_taps_uncached(kernel, device)
     if trim:
         out = _trim_taps(kernel, out)
@@ -304,7 +325,7 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation,
             sval = sval.detach().to(device=point_cloud.device, dtype=torch.float32).reshape(-1).contiguous()
         meta = meta._replace(sil_gt=sgt, sil_C=int(sC), sil_valid=sval)
     tx, ty, tz = _flat_taps(cfg, kernel, point_cloud.device)
-    proj, proj_depth, tr_pc, l2_grad, sil_loss, sil_win, sil_err = ops.ProjectFused.apply(
+    proj, proj_depth, tr_pc, l2_grad, sil_loss, sil_win, sil_err = ops.project_fused(
         point_cloud, transform, predicted_translation, scaling_factor, focal_length, tx, ty, tz, meta)
     state = {}
 

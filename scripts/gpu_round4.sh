@@ -29,6 +29,9 @@ if has bench; then
   B cfg5 --steps 30 --warmup 5 --config 5 --no-cpu-baseline
   B cfg1 --steps 50 --warmup 10 --config 1 --no-cpu-baseline
   B cfg1_eager --steps 50 --warmup 10 --config 1 --no-graph --no-cpu-baseline
+  DPC_BINDING=ctypes B cfg1_eager_ctypes --steps 50 --warmup 10 --config 1 --no-graph --no-cpu-baseline
+  B cfg2_eager --steps 50 --warmup 10 --no-graph --no-cpu-baseline
+  B cfg3_train --steps 20 --warmup 5 --config 3 --no-cpu-baseline
   B cfg3_train_graph --steps 20 --warmup 5 --config 3 --graph --no-cpu-baseline
 fi
 if has sigma; then

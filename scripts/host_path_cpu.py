@@ -20,6 +20,10 @@ emu = dpc_amd._capi.DpcLibrary(os.path.join(ROOT, "tests", "hipemu", "libdpc_emu
 emu.dpc_project_forward = lambda *a: 0
 emu.dpc_project_backward = lambda *a: 0
 dpc_amd._capi.set_library(emu)
+ext = dpc_amd._ext.module()           # the compiled binding (None with DPC_BINDING=ctypes or when it is not built)
+if ext is not None:
+    ext.set_dry_run(True)
+print("binding:", "compiled (csrc/dpc_torch.cpp)" if ext is not None else "ctypes (ops.ProjectFused)")
 torch.set_num_threads(1)
 
 B, N, D, K = 4, 1000, 64, 11

@@ -853,8 +853,10 @@ def test_recorded_step_follows_the_tap_counts():
         seen.append(m.effective_tap_counts()[0])
         sigma = dpc_amd.model_pc.get_smooth_sigma(cfg, gs)
         want = run(dpc_amd.smoothing_kernel(cfg, sigma, device=dev))
-        for a, b in zip(got, want):
-            assert torch.equal(a, b), (gs, sigma)
+        # point and scale gradients bit for bit (integer splat, fixed-order sums); the pose gradient is summed over
+        # work-groups with float atomics, whose order varies from launch to launch
+        assert torch.equal(got[0], want[0]) and torch.equal(got[2], want[2]), (gs, sigma)
+        assert float((got[1] - want[1]).abs().max()) <= 1e-5 * float(want[1].abs().max()), (gs, sigma)
     assert seen[0] == 21 and seen[-1] == 3 and all(a >= b for a, b in zip(seen, seen[1:]))
     assert step.records == len(set(seen))                 # one recording per tap count met
 
@@ -881,3 +883,39 @@ def test_bench_workload_switches(args):
     assert j["config"]["taps_run"] == want, j["config"]
     rf = j["roofline"]
     assert 0 < rf["frac"] <= 1.0 and 0 < rf["step_frac"] <= 1.0
+
+
+def test_compiled_binding_equals_ctypes_binding_on_the_device(monkeypatch):
+    """csrc/dpc_torch.cpp against ops.ProjectFused on the GPU: same library, same stream, same bits (point / scale
+    gradients and images exactly; the pose gradient to the float-atomic order), eagerly and inside a HIP graph."""
+    if dpc_amd._ext.module() is None:
+        pytest.skip("compiled binding not built (python __graft_entry__.py)")
+    dev = torch.device("cuda")
+    c = synth.config_inputs(1)
+    cfg = dpc_amd.default_config(vox_size=c["D"], pc_gauss_kernel_size=c["K"])
+    kern = dpc_amd.smoothing_kernel(cfg, c["sigma"], device=dev)
+    t = lambda a: torch.tensor(a, device=dev, requires_grad=True)
+    pc, pose, scale = t(c["pc"]), t(c["pose"]), t(c["scale"])
+    gt = torch.tensor(synth.disk_gt(c["B"], c["D"]), device=dev)
+
+    def run():
+        out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale, l2_target=(gt, 0.25))
+        return [out["proj"], out["proj_depth"]] + list(torch.autograd.grad(out["proj"], [pc, pose, scale], out["proj_l2_grad"]))
+
+    res = {}
+    for binding in ("compiled", "ctypes"):
+        monkeypatch.setenv("DPC_BINDING", "" if binding == "compiled" else "ctypes")
+        dpc_amd._ext.reset()
+        assert (dpc_amd._ext.module() is None) == (binding == "ctypes")
+        res[binding] = [x.clone() for x in run()]
+        if binding == "compiled":
+            step = dpc_amd.graphs.RecordedStep(run, world=1, device=dev)
+            res["recorded"] = [x.clone() for x in step()]
+    monkeypatch.delenv("DPC_BINDING")
+    dpc_amd._ext.reset()
+    for other in ("ctypes", "recorded"):
+        for i, (a, b) in enumerate(zip(res["compiled"], res[other])):
+            if i == 3:       # dpose: float atomics across work-groups
+                assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), other
+            else:
+                assert torch.equal(a, b), (other, i)

@@ -219,3 +219,89 @@ def test_grad_buckets_issue_in_bucket_order():
     assert b._next == 3
     b.finish()
     assert b._next == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the two bindings of the C ABI: ctypes (ops.ProjectFused) and the compiled one (csrc/dpc_torch.cpp)
+# ---------------------------------------------------------------------------------------------------------------
+def _project_both_ways(monkeypatch, **kw):
+    import dpc_amd
+    res = {}
+    for binding in ("compiled", "ctypes"):
+        monkeypatch.setenv("DPC_BINDING", "" if binding == "compiled" else "ctypes")
+        dpc_amd._ext.reset()
+        if binding == "compiled" and dpc_amd._ext.module() is None:
+            pytest.skip("compiled binding not built (python __graft_entry__.py)")
+        assert (dpc_amd._ext.module() is None) == (binding == "ctypes")
+        res[binding] = kw["run"]()
+    monkeypatch.delenv("DPC_BINDING")
+    dpc_amd._ext.reset()
+    return res["compiled"], res["ctypes"]
+
+
+def test_emu_compiled_binding_equals_ctypes_binding(emu, monkeypatch):
+    """Same inputs through csrc/dpc_torch.cpp and through ops.ProjectFused: every output and every gradient bit for bit
+    (both only marshal pointers into the same library), for the plain call, for translation + focal length + L2 epilogue +
+    fused dropout, and for in-kernel replication + candidate loss."""
+    import dpc_amd
+    B, N, D, K = 4, 200, 32, 5
+    inp = synth.make_inputs(B, N, 9)
+    cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K)
+    kern = dpc_amd.smoothing_kernel(cfg, 0.9, device="cpu")
+    t = lambda a: torch.tensor(a, requires_grad=True)
+    w = torch.tensor(np.random.default_rng(1).standard_normal((B, D, D, 1)).astype(np.float32))
+    wd = 0.1 * torch.tensor(np.random.default_rng(2).standard_normal((B, D, D, 1)).astype(np.float32))
+
+    def plain():
+        pc, pose, scale = t(inp["pc"]), t(inp["pose"]), t(inp["scale"])
+        out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale)
+        g = torch.autograd.grad([out["proj"], out["proj_depth"]], [pc, pose, scale], [w, wd])
+        return [out["proj"], out["proj_depth"], out["tr_pc"], *g]
+
+    def rich():
+        pc, pose, scale = t(0.5 * inp["pc"]), t(inp["pose"]), t(inp["scale"])
+        trans = t(0.02 * np.ones((B, 3), np.float32))
+        focal = t(np.full((B, 1), 1.9, np.float32))
+        gt = torch.tensor(synth.disk_gt(B, D))
+        out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, trans, None, kern, scaling_factor=scale, focal_length=focal,
+                                              l2_target=(gt, 0.25), point_dropout=(150, 77))
+        g = torch.autograd.grad(out["proj"], [pc, pose, trans, scale, focal], out["proj_l2_grad"])
+        return [out["proj"], out["proj_l2_grad"], *g]
+
+    def replicated():
+        clouds, pose, scale = t(inp["pc"][:2]), t(inp["pose"]), t(inp["scale"])
+        masks = torch.tensor(synth.disk_gt(2, 48))
+        out = dpc_amd.pointcloud_project_fast(cfg, clouds, pose, None, None, kern, scaling_factor=scale, views_per_cloud=2,
+                                              silhouette_target=(masks, 2, None))
+        g = torch.autograd.grad(out["proj_loss"], [clouds, pose, scale])
+        return [out["proj"], out["proj_loss"], out["winning_pose_candidates"], out["proj_inst_err"], *g]
+
+    for run in (plain, rich, replicated):
+        a, b = _project_both_ways(monkeypatch, run=run)
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y), run.__name__
+
+
+def test_emu_compiled_binding_keeps_the_error_behaviour(emu, monkeypatch):
+    """the exceptions a caller can see are those of the ctypes binding: ValueError for shapes / devices, TypeError for
+    dtypes, DpcError for a status code of the library"""
+    import dpc_amd
+    if dpc_amd._ext.module() is None:
+        pytest.skip("compiled binding not built")
+    cfg = dpc_amd.default_config(vox_size=32, pc_gauss_kernel_size=5)
+    kern = dpc_amd.smoothing_kernel(cfg, 0.9, device="cpu")
+    inp = synth.make_inputs(2, 50, 3)
+    pc, pose = torch.tensor(inp["pc"]), torch.tensor(inp["pose"])
+    with pytest.raises(ValueError):
+        dpc_amd.pointcloud_project_fast(cfg, pc[..., :2], pose, None, None, kern)
+    with pytest.raises(ValueError, match="quaternion"):
+        dpc_amd.pointcloud_project_fast(cfg, pc, pose[:, :3], None, None, kern)
+    with pytest.raises(TypeError):
+        dpc_amd.pointcloud_project_fast(cfg, pc.double(), pose, None, None, kern)
+    with pytest.raises(ValueError):
+        dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=torch.ones(3, 1))
+    cfg48 = dpc_amd.default_config(vox_size=48, pc_gauss_kernel_size=5)     # generic path: no fused dropout
+    with pytest.raises(ValueError, match="fused point dropout"):
+        dpc_amd.pointcloud_project_fast(cfg48, pc, pose, None, None, dpc_amd.smoothing_kernel(cfg48, 0.9, device="cpu"),
+                                        point_dropout=(10, 1))
