@@ -1,52 +1,52 @@
-// dpc_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) and the
-// C ABI (include/dpc_hip.h) of the differentiable point-cloud projector.
+// dpc_kernels.hip -- main translation unit of the MI355X (gfx950 / CDNA4, wave64) differentiable point-cloud
+// projector: the C ABI (include/dpc_hip.h), the launch logic (host_launch.inc) and every kernel WITHOUT a Gaussian
+// tap-count parameter.  The kernels unrolled for a compile-time tap count K (3 .. 21 odd) are compiled by tu_taps.hip,
+// one translation unit per K, and reached through dpck::TapKernels<K> (host_launch_k.inc).
 //
-// Fused hot path (power-of-two D in [32,256], K in {5,11,21}); grids are
-// [B,Dz,D,D], x fastest; V = bytes of one grid of one view.  Planes that hold no
-// trilinear mass (one bit per plane, from the depth-cell histogram) are neither
-// written nor read anywhere on this path:
+// Fused hot path (power-of-two D in [32,256], Kx == Ky in {3..21 odd}, Dz <= 256); grids are [B,Dz,D,D], x fastest;
+// V = bytes of one grid of one view.  Planes that hold no trilinear mass (one bit per plane, from the depth-cell
+// histogram) are neither written nor read anywhere on this path:
 //
-//   forward   k_zsort      WG/view: camera transform (quaternion or matrix) ->
-//                          tr_pc, LDS counting sort of the points by depth cell,
-//                          plane-occupancy bits
-//             k_splat_xy   WG/(view, plane, y-strip): zero an LDS tile, ds_add_f32
-//                          the plane's points, record one clip-gradient bit per
-//                          touched corner, clip, x-blur (halo from neighbour
-//                          lanes, ds_bpermute), y-blur (rotating register FIR)
-//                          -> xy-blurred plane.                      writes 1 V
-//             k_zfwd       thread = CX adjacent rays, streams z once: register
-//                          z-FIR, scale/clip, DRC collapse as a running
-//                          transmittance product (no log/exp), silhouette + depth
-//                          + two fp64 sums per ray.  With <= 11 z taps it only
-//                          READS: the xy-blurred grid itself is what is saved for
-//                          backward (storing G2 was 41 % of its time).  reads 1 V
-//   backward  k_zbwd       same walk: (re-applies the z-FIR to the saved xy grid,
-//                          bit for bit,) DRC VJP (suffix sum = saved total - fp64
-//                          prefix), scale/clip masks, dscale, z-FIR adjoint.
-//                                                               reads 1 V, writes 1 V
-//             k_gather_yx  WG/(view, plane, y-strip): rows -> LDS, y-blur in place, sparse
-//                          x-blur + clip bits + trilinear gather at the plane's
-//                          points -> per-corner partial d(tr_pc).   reads ~1.2 V
-//             k_points_bwd thread/point: sum partials, camera-transform VJP,
-//                          block reduction of dq/dt/df into a [B,16] accumulator
-//                          (cleared by k_zbwd's first work-group per view)
-//             k_pose_finalize  quaternion normalisation Jacobian; dscale = fixed-order
-//                          sum of k_zbwd's per-work-group partials
+//   forward   k_zsort       WG/view (N <= 8192; k_zhist + k_zscatter, several WGs per view, beyond): camera transform
+//                           (quaternion or matrix) -> tr_pc, LDS counting sort of the points by depth cell into
+//                           16-byte records (w, v, u, n), inverse map, plane-occupancy bits; the fused dropout's keyed
+//                           permutation decides which points survive; in-kernel replication over views
+//             k_splat_xy    WG/(view, plane, y-strip): zero an LDS tile, FIXED-POINT ds_add_u32 splat of the plane's
+//                           points (order-independent: bitwise reproducible), one clip-gradient bit per touched
+//                           corner, clip, x-blur (a grid row = one 16-lane DPP row, halo through row_shr / row_shl with
+//                           bound_ctrl), y-blur from a register window -> xy-blurred plane.          writes 1 V
+//             k_zfwd        thread = 2 adjacent rays, streams z once: packed register z-FIR, scale / clip, DRC collapse
+//                           as a running transmittance product (no log / exp), silhouette + depth + fp64 ray sums,
+//                           optionally the L2 loss gradient or the per-work-group partials of the candidate loss.  Up
+//                           to 19 z taps it only READS: the xy-blurred grid itself is what is saved for backward;
+//                           at 21 it also writes G2.                                            reads 1 V (+ 1 V)
+//   backward  k_zbwd        same walk: (re-applies the z-FIR to the saved xy grid, bit for bit,) DRC VJP (suffix sum =
+//                           saved total - fp64 prefix), scale / clip masks, per-WG dscale partials, z-FIR adjoint
+//                           (taps reversed); forms the candidate loss's gradient itself.        reads 1 V, writes 1 V
+//             k_gather_yx   WG/(view, plane, y-strip): rows -> LDS, y-blur adjoint in place, x-blur adjoint (dense in
+//                           registers while staging for one-strip planes with many points, per-point windows otherwise)
+//                           + clip bits + trilinear gather -> per-(corner plane[, row]) partial d(tr_pc).  reads ~1 V
+//             k_points_bwd_sorted / k_points_bwd_slots   thread = point (caller's order; partials fetched through
+//                           slot_of) or thread = slot (multi-strip grids: records and partials stream, the gradient
+//                           store scatters): camera-transform VJP, block reduction of dq / dt / df into a [B,16]
+//                           accumulator (cleared by k_zbwd's first work-group per view) with returning atomics; the
+//                           LAST work-group of a view finishes it (quaternion Jacobian, fixed-order dscale sum)
+//             k_sum_views   (views_per_cloud > 1) point gradient of a cloud = fixed-order sum over its instances
 //
-// Outside the headline path, same ABI: k_sil_* (silhouette loss epilogue), k_gv_*
-// (exact Gaussian voxeliser, the reference's pc_fast:false splat), k_nn_distance
-// (nearest neighbour / Chamfer), k_scatter_vals / k_gather_vals (RGB channels).
+// Outside the headline path, same ABI: k_sil_* (silhouette loss epilogue), k_student_loss, k_gv_* (exact Gaussian
+// voxeliser, the reference's pc_fast:false splat), k_nn_distance (nearest neighbour / Chamfer), k_scatter_vals /
+// k_gather_vals (RGB channels), k_copy* / k_read_sum / k_fill (bench.py's HBM ceilings, PMC calibration).
 //
 // Generic path (any D, odd K <= 63, max-collapse, no blur, stage-level API):
-//   k_points_fwd (transform + 8 global_atomic_add_f32 into zero-filled G0),
-//   k_blur_xy_stream / k_blur_plane (plane blur, LDS-free / LDS-tiled),
-//   k_blur_z / k_blur_z_generic, k_scatter, k_gather, k_max_fwd/bwd.
+//   k_points_fwd (transform + 8 global_atomic_add_f32 into zero-filled G0), k_blur_xy_stream / k_blur_plane (plane
+//   blur, LDS-free / LDS-tiled), k_blur_z / k_blur_z_generic, k_scatter, k_gather, k_points_bwd + k_pose_finalize,
+//   k_max_fwd / k_max_bwd.
 //
-// No MFMA: this is scatter / stencil / scan work bounded by HBM (and, before
-// the rewrites recorded in profiles/, by VALU issue and LDS crossbar time).
+// No MFMA: this is scatter / stencil / scan work bounded by HBM (and, before the rewrites recorded in profiles/, by
+// VALU issue and LDS crossbar time).
 //
-// The same source compiles for the CPU-only test tier with -DDPC_EMU (see
-// tests/hipemu/hip_emu.h); that build is never loaded by the product.
+// The same sources compile for the CPU-only test tier with -DDPC_EMU (tests/hipemu/hip_emu.h); that build is never
+// loaded by the product.
 
 #include "k_prelude.inc"
 

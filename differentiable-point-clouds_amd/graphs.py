@@ -14,6 +14,10 @@ What the recipe has to get right (each item was a failure on a real box or is a 
   the default (global) mode turns into a capture error;
 * a capture that fails half way leaves the rank's streams in capture mode and its peers waiting inside a collective:
   with more than one rank the error is raised, not swallowed;
+* nothing may keep the autograd graph of an EARLIER eager call of the same leaves alive while the step is recorded (a
+  list of outputs that still carry grad_fn, say): torch then synchronises the capture stream with the stream that graph
+  was built on ("AccumulateGrad node's stream does not match ..."), which on ROCm ends in a segfault when the capture
+  closes.  Keep detached copies;
 * the recorded kernels are those of ONE set of launch decisions.  ``key`` (a callable) names the decisions that can
   move between replays -- for the projector the effective tap counts of the annealed blur
   (``ModelPointCloud.effective_tap_counts``).  When the key changes the step is run eagerly once (that IS the step of

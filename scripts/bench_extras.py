@@ -58,6 +58,30 @@ def main():
     res["gauss_voxelize_fwd_ms_per_view"] = timed(gv_fwd, 5, 1) / 4
     res["gauss_voxelize_fwd_bwd_ms_per_view"] = timed(gv_step, 5, 1) / 4
     res["gauss_voxelize_fwd_gflops"] = 2 * 8000 * 64 ** 3 / (res["gauss_voxelize_fwd_ms_per_view"] * 1e-3) / 1e9
+    # the projector with a depth-image gradient coming in (proj_depth_weight > 0, dpc/util/losses.py:113-136): the collapse VJP
+    # then runs its HAS_GD instantiation (gamma_j = g + gd psi_j per plane) -- per-kernel times next to the plain step
+    import bench
+    lib = dpc_amd.get_library()
+    for name, cfg_id, B, sigma in (("cfg2", 2, None, None), ("training_shape", 3, 320, 3.0), ("training_shape_sigma0.8", 3, 320, 0.8)):
+        case = bench.build_case(cfg_id, B, torch.device(dev), sigma=sigma)
+        gd = torch.randn(case["B"], case["D"], case["D"], 1, device=dev) * 1e-3
+
+        def depth_step():
+            out = dpc_amd.pointcloud_project_fast(case["cfg"], case["pc"], case["pose"], None, None, case["kern"],
+                                                  scaling_factor=case["scale"], l2_target=(case["gt"], 1.0 / case["B"]))
+            return torch.autograd.grad([out["proj"], out["proj_depth"]], [case["pc"], case["pose"], case["scale"]],
+                                       [out["proj_l2_grad"], gd])
+        for label, fn in (("plain", lambda: bench.step(case)), ("with_depth_gradient", depth_step)):
+            ms = timed(fn, 20, 5)
+            lib.profile(True)
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            per = {}
+            for lab, t in lib.profile_records():
+                per[lab] = per.get(lab, 0.0) + t / 5
+            lib.profile(False)
+            res["projector_%s_%s" % (name, label)] = {"ms_per_step": ms, "kernel_ms": {k: round(v, 4) for k, v in sorted(per.items())}}
     print(json.dumps(res))
 
 
