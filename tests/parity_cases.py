@@ -88,6 +88,9 @@ FUSED_CASES = [
     (2, 400, 64, 64, 21, 3.0, False, False),     # the shipped experiments' kernel size
     (2, 40, 64, 64, 5, 0.8, False, False),       # fewer points than one wave
     (1, 8300, 32, 32, 5, 0.8, True, False),      # more than 8 x 1024 points: the two-kernel depth sort; > 512 points per plane
+    # round 4: grids narrower than the power-of-two lane geometry (rows padded inside the kernels)
+    (2, 600, 48, 48, 5, 0.9, False, False),      # 48 on the 64-wide geometry: one strip per plane
+    (2, 300, 24, 24, 5, 0.8, True, False),       # 24 on the 32-wide one
 ]
 
 
@@ -110,6 +113,10 @@ FUSED_CASES_GPU = FUSED_CASES + [
     (1, 4000, 64, 64, 17, 2.9, False, False),
     (1, 1500, 128, 128, 19, 3.2, False, False),
     (1, 1200, 128, 64, 19, 3.2, False, False),   # vox_size_z = 64 at 128: Kz = 9
+    (2, 3000, 96, 96, 11, 1.6, False, False),    # 96 on the 128-wide geometry: two strips, the second half empty below row 96
+    (2, 6000, 48, 48, 21, 3.0, True, True),      # 48 on 64 with 21 taps: dense gather flow on padded rows
+    (1, 2000, 80, 80, 9, 1.4, False, False),     # 80 on 128 (10 of 16 lanes)
+    (1, 3000, 160, 64, 7, 1.2, False, False),    # 160 on 256, shallow grid
 ]
 DENSE_GATHER_CASE_EMU = (1, 3000, 32, 32, 5, 0.8, False, False)    # ~150+ points per occupied plane at D = 32
 

@@ -305,3 +305,27 @@ def test_emu_compiled_binding_keeps_the_error_behaviour(emu, monkeypatch):
     with pytest.raises(ValueError, match="fused point dropout"):
         dpc_amd.pointcloud_project_fast(cfg48, pc, pose, None, None, dpc_amd.smoothing_kernel(cfg48, 0.9, device="cpu"),
                                         point_dropout=(10, 1))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# grids narrower than the fused kernels' power-of-two lane geometry (default_config.yaml:77 accepts any vox_size)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [(2, 600, 48, 48, 5, 0.9, False, False), (2, 300, 24, 24, 5, 0.8, True, False),
+                                  (1, 500, 40, 40, 7, 1.2, False, True), (1, 400, 96, 48, 5, 0.9, False, False)])
+def test_emu_padded_grids_take_the_fused_path(emu, case):
+    """vox_size 48 / 24 / 40 (on the 64- / 32- / 64-wide geometry, one strip per plane) and 96 (on the 128-wide one, two
+    strips): the fused front / back end with the lanes and rows beyond the grid masked, forward and all gradients against
+    the float64 NumPy oracle (the helper also asserts that the fused path -- not the generic one -- took the shape)."""
+    import parity_cases
+    parity_cases.fused_path_against_numpy_oracle("cpu", *case)
+
+
+def test_fused_width_rule():
+    """which vox_size values the fused path takes: D fills whole lanes of the next power-of-two geometry"""
+    import ctypes
+    import dpc_amd
+    lib = dpc_amd.get_library()
+    P = dpc_amd._capi.DpcParams(2.0, 1.875, 1e-5, 10.0, 1, 0, 0, 0, 0)
+    fused = lambda D: bool(lib.dpc_saved_layout(ctypes.byref(dpc_amd._capi.DpcShape(2, 100, 32, D, 5, 5, 5)), ctypes.byref(P)) & 2)
+    assert all(fused(D) for D in (20, 24, 28, 32, 40, 48, 56, 64, 72, 80, 96, 112, 128, 144, 160, 192, 240, 256))
+    assert not any(fused(D) for D in (16, 18, 30, 33, 50, 66, 100, 130, 136, 257, 260))
