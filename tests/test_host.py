@@ -87,7 +87,7 @@ def test_c_abi_argument_validation_without_gpu():
     # the fused dropout is refused (not silently ignored) off the fused path; point_index must be 16-byte aligned
     one = ctypes.c_void_p(256)
     Pd = _capi.DpcParams(2.0, 1.875, 1e-5, 10.0, 1, 0, 0, 3, 7)
-    rc = lib.dpc_project_forward(null, ctypes.byref(_capi.DpcShape(1, 10, 20, 20, 5, 5, 5)), ctypes.byref(Pd), one, one, null,
+    rc = lib.dpc_project_forward(null, ctypes.byref(_capi.DpcShape(1, 10, 18, 18, 5, 5, 5)), ctypes.byref(Pd), one, one, null,
                                  null, null, one, one, one, one, one, null, null, one, one, one, null, one, 10 ** 9)
     assert rc == -5                                      # DPC_E_MODE
     rc = lib.dpc_project_forward(null, ctypes.byref(_capi.DpcShape(1, 10, 32, 32, 5, 5, 5)), ctypes.byref(P), one, one, null,

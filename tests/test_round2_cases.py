@@ -118,7 +118,7 @@ def test_silhouette_loss_argument_validation(emu):
 
 
 def test_fused_dropout_needs_the_fused_path(emu):
-    cfg = dpc_amd.default_config(vox_size=20, pc_gauss_kernel_size=5)
+    cfg = dpc_amd.default_config(vox_size=18, pc_gauss_kernel_size=5)
     pc = torch.zeros(1, 50, 3)
     q = torch.tensor([[1.0, 0, 0, 0]])
     with pytest.raises(ValueError, match="fused"):

@@ -301,7 +301,7 @@ def test_emu_compiled_binding_keeps_the_error_behaviour(emu, monkeypatch):
         dpc_amd.pointcloud_project_fast(cfg, pc.double(), pose, None, None, kern)
     with pytest.raises(ValueError):
         dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=torch.ones(3, 1))
-    cfg48 = dpc_amd.default_config(vox_size=48, pc_gauss_kernel_size=5)     # generic path: no fused dropout
+    cfg48 = dpc_amd.default_config(vox_size=50, pc_gauss_kernel_size=5)     # generic path (50 does not fill whole lanes): no fused dropout
     with pytest.raises(ValueError, match="fused point dropout"):
         dpc_amd.pointcloud_project_fast(cfg48, pc, pose, None, None, dpc_amd.smoothing_kernel(cfg48, 0.9, device="cpu"),
                                         point_dropout=(10, 1))
