@@ -33,17 +33,21 @@ if has bench; then
   B cfg2_eager --steps 50 --warmup 10 --no-graph --no-cpu-baseline
   B cfg3_train --steps 20 --warmup 5 --config 3 --no-cpu-baseline
   B cfg3_train_graph --steps 20 --warmup 5 --config 3 --graph --no-cpu-baseline
+  B cfg3_train_graph_keep0.07 --steps 20 --warmup 5 --config 3 --graph --keep-prob 0.07 --no-cpu-baseline
+  B cfg2_ball --steps 30 --warmup 5 --points ball --no-cpu-baseline
+  timeout 300 python examples/chair_unsupervised/train_step.py --steps 60 --warmup 5 --keep-prob 0.07 --scheduled --max-steps 65 --graph > "$OUT/09_train_step_example_graph.json" 2> "$OUT/09_train_step_example_graph.err"; echo "example graph rc=$?"
+  timeout 300 python scripts/bench_extras.py 2>/dev/null | tail -1 > "$OUT/09_bench_extras.json"; echo "extras rc=$?"
 fi
 if has sigma; then
   for S in 3.0 1.5 0.8 0.3; do
     B cfg3p_sigma$S --steps 30 --warmup 5 --config 3 --projector-only --sigma $S --no-cpu-baseline
   done
-  # A/B: which state layout (G2 saved, or the xy grid saved + second z-FIR in k_zbwd) wins between 11 and 21 taps
-  for S in 3.0 1.5 1.2 1.0; do
-    DPC_SAVE_XY_MAXK=21 B cfg3p_sigma${S}_savexy --steps 30 --warmup 5 --config 3 --projector-only --sigma $S --no-cpu-baseline
-  done
+  # A/B of the state layout at the two ends of the xy-saving range (default: xy grid saved up to 19 taps, G2 at 21)
+  DPC_SAVE_XY_MAXK=21 B cfg3p_sigma3.0_savexy --steps 30 --warmup 5 --config 3 --projector-only --sigma 3.0 --no-cpu-baseline
+  DPC_SAVE_XY_MAXK=11 B cfg3p_sigma1.2_saveg2 --steps 30 --warmup 5 --config 3 --projector-only --sigma 1.2 --no-cpu-baseline
   B cfg3p_sigma1.2 --steps 30 --warmup 5 --config 3 --projector-only --sigma 1.2 --no-cpu-baseline
   B cfg3p_sigma1.0 --steps 30 --warmup 5 --config 3 --projector-only --sigma 1.0 --no-cpu-baseline
+  B cfg3p_n560 --steps 30 --warmup 5 --config 3 --projector-only --num-points 560 --no-cpu-baseline
   B cfg3_train_graph_sigma0.8 --steps 20 --warmup 5 --config 3 --graph --sigma 0.8 --no-cpu-baseline
 fi
 if has generic; then
