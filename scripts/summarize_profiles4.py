@@ -17,7 +17,7 @@ from collections import defaultdict
 out = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LABEL = {"k_zsort": "zsort", "k_zhist": "zhist", "k_zscatter": "zscatter", "k_splat_xy": "splat_xy", "k_zfwd": "zfwd",
-         "k_zbwd": "zbwd", "k_gather_yx": "gather_yx", "k_points_bwd_sorted": "points_bwd", "k_pose_finalize": "pose_finalize",
+         "k_zbwd": "zbwd", "k_gather_yx": "gather_yx", "k_points_bwd_sorted": "points_bwd", "k_points_bwd_slots": "points_bwd", "k_pose_finalize": "pose_finalize",
          "k_points_fwd": "points_fwd", "k_points_bwd": "points_bwd", "k_blur_plane": "blur_plane", "k_blur_xy_stream": "blur_xy",
          "k_blur_z": "blur_z", "k_blur_z_generic": "blur_z", "k_sum_views": "sum_views"}
 
