@@ -73,6 +73,13 @@ int64_t open_library(const std::string& path, bool host_memory) {
   return (int64_t)g_apis.size() - 1;
 }
 
+// a copy of the library's entry points (taken under the lock: open_library may grow the table meanwhile)
+Api api_of(int64_t lib) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  TORCH_CHECK(lib >= 0 && (size_t)lib < g_apis.size(), "unknown library id ", lib);
+  return g_apis[(size_t)lib];
+}
+
 inline size_t a256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 // Everything about one (library, B, N, grid, taps, collapse) combination that does not change from call to call
@@ -86,7 +93,8 @@ struct Plan {
 };
 std::unordered_map<std::string, Plan> g_plans;
 
-const Plan& plan_for(int64_t lib, const Api& api, int B, int N, int Dz, int D, int collapse, int Kx, int Ky, int Kz) {
+// (returned by value: the cache may be cleared by another thread)
+Plan plan_for(int64_t lib, const Api& api, int B, int N, int Dz, int D, int collapse, int Kx, int Ky, int Kz) {
   char key[160];
   snprintf(key, sizeof key, "%ld/%d/%d/%d/%d/%d/%d/%d/%d", (long)lib, B, N, Dz, D, collapse, Kx, Ky, Kz);
   std::lock_guard<std::mutex> lk(g_mu);
@@ -190,8 +198,7 @@ class ProjectFusedFn : public torch::autograd::Function<ProjectFusedFn> {
                                const optional<Tensor>& sil_valid_in, int64_t lib, int64_t Dz, int64_t D, double cd, double f, double eps,
                                double max_depth, bool quat, int64_t collapse, int64_t dropout_keep, int64_t dropout_seed,
                                double l2_weight, int64_t views_per_cloud, int64_t sil_C, bool poison) {
-    TORCH_CHECK(lib >= 0 && (size_t)lib < g_apis.size(), "unknown library id");
-    const Api api = g_apis[(size_t)lib];
+    const Api api = api_of(lib);
     const Meta m{lib, Dz, D, cd, f, eps, max_depth, quat, collapse, dropout_keep, dropout_seed, l2_weight, views_per_cloud, sil_C, poison};
     TORCH_CHECK_VALUE(pc_in.dim() == 3 && pc_in.size(2) == 3, "point_cloud must be [B,N,3], got ", pc_in.sizes());
     const int64_t R = views_per_cloud > 1 ? views_per_cloud : 1;
@@ -226,7 +233,7 @@ class ProjectFusedFn : public torch::autograd::Function<ProjectFusedFn> {
       TORCH_CHECK_VALUE(K[i] % 2 == 1, "even Gaussian kernel sizes are not supported (TF pads them asymmetrically)");
       TORCH_CHECK_VALUE(K[i] <= DPC_MAX_TAPS, "kernel size ", K[i], " > ", DPC_MAX_TAPS);
     }
-    const Plan& plan = plan_for(lib, api, (int)B, (int)N, (int)Dz, (int)D, (int)collapse, K[0], K[1], K[2]);
+    const Plan plan = plan_for(lib, api, (int)B, (int)N, (int)Dz, (int)D, (int)collapse, K[0], K[1], K[2]);
     const bool fused = (plan.layout & 2) != 0;
     TORCH_CHECK_VALUE(R == 1 || fused, "views_per_cloud needs the fused path (vox_size a multiple of 4 that fills whole lanes of the next power of two in [32,256], odd kernel size 3..21)");
     if (tgt.defined()) {
@@ -340,10 +347,10 @@ class ProjectFusedFn : public torch::autograd::Function<ProjectFusedFn> {
     const std::vector<int64_t> iv = sd["i"].toIntVector();
     const std::vector<double> dv = sd["d"].toDoubleVector();
     const Meta m{iv[0], iv[1], iv[2], dv[0], dv[1], dv[2], dv[3], iv[3] != 0, iv[4], iv[5], iv[6], dv[4], iv[7], iv[8], iv[9] != 0};
-    const Api api = g_apis[(size_t)m.lib];
+    const Api api = api_of(m.lib);
     const int64_t R = m.views_per_cloud > 1 ? m.views_per_cloud : 1;
     const int64_t B = pc.size(0) * R, N = pc.size(1);
-    const Plan& plan = plan_for(m.lib, api, (int)B, (int)N, (int)m.Dz, (int)m.D, (int)m.collapse, (int)iv[10], (int)iv[11], (int)iv[12]);
+    const Plan plan = plan_for(m.lib, api, (int)B, (int)N, (int)m.Dz, (int)m.D, (int)m.collapse, (int)iv[10], (int)iv[11], (int)iv[12]);
     size_t gi = 2;
     Tensor dproj = contig(g[0]), dtr = contig(g[1]);
     Tensor ddepth = iv[13] ? contig(g[gi++]) : Tensor();

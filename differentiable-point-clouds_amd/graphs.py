@@ -52,8 +52,8 @@ class RecordedStep(object):
         torch.cuda.current_stream(self.device).wait_stream(side)
 
     def _record(self):
-        self.graph, self.out = None, None            # frees the previous recording's memory pool
-        torch.cuda.synchronize(self.device)
+        torch.cuda.synchronize(self.device)          # nothing of the previous recording is in flight any more ...
+        self.graph, self.out = None, None            # ... before its memory pool is released
         if self.world > 1:
             dd.barrier(self.device)
         graph = torch.cuda.CUDAGraph()
