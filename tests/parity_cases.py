@@ -419,7 +419,7 @@ def asymmetric_filters_against_cpu_oracle(dev, D, K):
     assert maxabs(gv.cpu().numpy(), cgv.numpy()) < 2e-5 * float(np.abs(cgv.numpy()).max())
 
 
-def fused_dropout_equals_explicit_subset(dev, B=3, N=420, D=32, K=5, keep=137, seed=20260927):
+def fused_dropout_equals_explicit_subset(dev, B=3, N=420, D=32, K=5, keep=137, seed=20260927, extras=True):
     """pointcloud_project_fast(point_dropout=(keep, seed)) == the projector run on the explicitly gathered
     subset that oracle/dropout_ref.py predicts (per-instance, exactly `keep` points, without replacement):
     forward image, gradients of the kept points, exact zeros for the dropped ones."""
@@ -450,6 +450,8 @@ def fused_dropout_equals_explicit_subset(dev, B=3, N=420, D=32, K=5, keep=137, s
     assert relerr(g[1].cpu().numpy(), rg[1].cpu().numpy()) < 1e-5
     assert relerr(g[2].cpu().numpy(), rg[2].cpu().numpy()) < 1e-5
     assert out["tr_pc"].shape == (B, N, 3)
+    if not extras:      # (the argument checks and the device-resident draw below do not depend on the sizes)
+        return
     # keep >= N means "no dropout"; keep == 0 (an empty cloud in the reference, "off" to the kernels) is refused
     with pytest.raises(ValueError):
         dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale, point_dropout=(0, 1))
