@@ -17,7 +17,7 @@ import torch
 from . import ops
 from .util.gauss_kernel import gauss_smoothen_image, smoothing_kernel
 from .util.losses import (add_drc_loss, add_proj_depth_loss, add_proj_rgb_loss,  # noqa: F401
-                          resize_images_bilinear_tf1)
+                          resize_images_bicubic_tf1, resize_images_bilinear_tf1)
 from .util.point_cloud import pc_point_dropout, pointcloud_project, pointcloud_project_fast
 from .util.quaternion import quaternion_rotate as q_rotate
 
@@ -413,8 +413,9 @@ class ModelPointCloud(object):
         pred = outputs["projs"]
         gt_size, pred_size = gt.shape[1], pred.shape[1]
         assert gt_size >= pred_size, "GT size should not be higher than prediction size"
-        if gt_size > pred_size and cfg.bicubic_gt_downsampling:
-            raise NotImplementedError("bicubic GT downsampling")
+        if gt_size > pred_size and cfg.bicubic_gt_downsampling:             # model_pc.py:392-397
+            gt = resize_images_bicubic_tf1(gt, [pred_size, pred_size])
+            gt_size = pred_size
         if cfg.pc_gauss_filter_gt:                                          # model_pc.py:398-404
             if getattr(self, "_graph_replay", False):
                 # the GT blur takes sigma as a host number and a host branch on it: a recorded step would freeze both

@@ -30,6 +30,54 @@ def resize_images_bilinear_tf1(images, size):
     return top * (1 - yl) + bot * yl
 
 
+_BICUBIC_TABLE = {}
+
+
+def _bicubic_table(device):
+    """resize_bicubic_op.cc's coefficient table (TF r1.x): 1024 steps of the cubic convolution kernel with A = -0.75,
+    entry 2 i = k(i / 1024), entry 2 i + 1 = k(1 + i / 1024), evaluated in double on a float x, stored as float."""
+    key = str(device)
+    if key not in _BICUBIC_TABLE:
+        a = -0.75
+        x = (torch.arange(1025, dtype=torch.float64) / 1024.0).to(torch.float32).to(torch.float64)
+        near = ((a + 2) * x - (a + 3)) * x * x + 1
+        x1 = (x.to(torch.float32) + 1.0).to(torch.float64)          # `x += 1.0` on the float
+        far = ((a * x1 - 5 * a) * x1 + 8 * a) * x1 - 4 * a
+        _BICUBIC_TABLE[key] = (near.to(torch.float32).to(device), far.to(torch.float32).to(device))
+    return _BICUBIC_TABLE[key]
+
+
+def resize_images_bicubic_tf1(images, size):
+    """tf.image.resize_images(..., ResizeMethod.BICUBIC) as TF1 computes it (model_pc.py:392-397 with
+    cfg.bicubic_gt_downsampling): the ResizeBicubic op with align_corners=False and the legacy scaler -- source position
+    = dst * (in / out) in float, four taps at floor - 1 .. floor + 2 clamped to the image, weights looked up in a
+    1024-step table of the A = -0.75 cubic kernel at lrint(frac * 1024), x pass then y pass in float32.
+    Restated from the published op (tensorflow/core/kernels/resize_bicubic_op.cc); PARITY UNPINNED: no TensorFlow
+    binary or golden vector for this branch exists here (the reference switches it off by default,
+    default_config.yaml:96).  images [B,H,W,C] -> [B,size0,size1,C] float32."""
+    n, ih, iw, c = images.shape
+    oh, ow = int(size[0]), int(size[1])
+    near, far = _bicubic_table(images.device)
+    img = images.to(torch.float32)
+
+    def axis(o, i):
+        scale = torch.tensor(float(i), dtype=torch.float32) / torch.tensor(float(o), dtype=torch.float32)
+        loc = torch.arange(o, dtype=torch.float32) * scale
+        lo = torch.floor(loc)
+        off = torch.round((loc - lo) * 1024.0).to(torch.int64)       # lrintf: half to even, as torch.round
+        lo = lo.to(torch.int64)
+        idx = torch.stack([torch.clamp(lo + d, 0, i - 1) for d in (-1, 0, 1, 2)]).to(images.device)
+        off = off.to(images.device)
+        w = torch.stack([far[off], near[off], near[1024 - off], far[1024 - off]])
+        return idx, w
+    xi, xw = axis(ow, iw)
+    yi, yw = axis(oh, ih)
+    xw = xw.view(4, 1, 1, ow, 1)
+    cols = img[:, :, xi[0]] * xw[0] + img[:, :, xi[1]] * xw[1] + img[:, :, xi[2]] * xw[2] + img[:, :, xi[3]] * xw[3]
+    yw = yw.view(4, 1, oh, 1, 1)
+    return cols[:, yi[0]] * yw[0] + cols[:, yi[1]] * yw[1] + cols[:, yi[2]] * yw[2] + cols[:, yi[3]] * yw[3]
+
+
 def resize_images_nearest_tf1(images, size):
     """TF1 legacy nearest neighbour: src = floor(dst * in/out)."""
     n, ih, iw, c = images.shape

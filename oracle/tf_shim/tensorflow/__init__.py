@@ -435,6 +435,44 @@ def where(c, a, b):
     return _wrap(_torch.where(c, a, b))
 
 
+def _resize_bicubic_legacy(images, oh, ow):
+    """ResizeBicubic, align_corners=False, legacy scaler (tensorflow/core/kernels/resize_bicubic_op.cc, r1.x), pixel by
+    pixel as the op's reference loop: in = out * (in_size / out_size) [float]; taps floor(in) - 1 .. + 2 clamped; weights
+    from the 1024-entry table of the A = -0.75 cubic kernel at lrintf(frac * 1024); rows first along x, then along y."""
+    import numpy as _np
+    a = -0.75
+    tab = _np.zeros((1025, 2), _np.float32)
+    for i in range(1025):
+        x = _np.float32(i * 1.0 / 1024)
+        tab[i, 0] = ((a + 2) * float(x) - (a + 3)) * float(x) * float(x) + 1
+        x = _np.float32(x + _np.float32(1.0))
+        tab[i, 1] = ((a * float(x) - 5 * a) * float(x) + 8 * a) * float(x) - 4 * a
+
+    def taps(o, i):
+        scale = _np.float32(i) / _np.float32(o)
+        out = []
+        for k in range(o):
+            loc = _np.float32(k) * scale
+            lo = int(_np.floor(loc))
+            off = int(_np.rint(_np.float32(loc - _np.float32(lo)) * _np.float32(1024)))
+            w = (tab[off, 1], tab[off, 0], tab[1024 - off, 0], tab[1024 - off, 1])
+            idx = tuple(min(max(lo + d, 0), i - 1) for d in (-1, 0, 1, 2))
+            out.append((idx, w))
+        return out
+    src = images.detach().cpu().numpy().astype(_np.float32)
+    n, ih, iw, c = src.shape
+    ty, tx = taps(oh, ih), taps(ow, iw)
+    res = _np.zeros((n, oh, ow, c), _np.float32)
+    for y, (yi, yw) in enumerate(ty):
+        for x, (xi, xw) in enumerate(tx):
+            rows = []
+            for r in yi:
+                v = src[:, r, xi[0]] * xw[0] + src[:, r, xi[1]] * xw[1] + src[:, r, xi[2]] * xw[2] + src[:, r, xi[3]] * xw[3]
+                rows.append(v.astype(_np.float32))
+            res[:, y, x] = rows[0] * yw[0] + rows[1] * yw[1] + rows[2] * yw[2] + rows[3] * yw[3]
+    return _torch.tensor(res)
+
+
 class _Image(object):
     class ResizeMethod(object):
         BILINEAR = 0
@@ -444,9 +482,11 @@ class _Image(object):
     def resize_images(images, size, method=0):
         """TF1 tf.image.resize_images, align_corners=False (legacy): source
         coordinate = dst * (in/out), no half-pixel offset, bilinear."""
-        assert method == 0, "only bilinear"
         n, ih, iw, c = [int(s) for s in images.size()]
         oh, ow = int(size[0]), int(size[1])
+        if method == 2:
+            return _wrap(_resize_bicubic_legacy(images, oh, ow))
+        assert method == 0, "bilinear or bicubic"
 
         def axis(o, i):
             src = _torch.arange(o, dtype=_torch.float64) * (i / o)

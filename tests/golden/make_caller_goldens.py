@@ -80,17 +80,20 @@ def loss_cases():
     1/2/3, non-integer GT resize ratios, per-group valid_samples weights.  -> caller_loss.npz"""
     rng = np.random.default_rng(77)
     out = {}
+    # (the bicubic cases come last: the earlier cases keep their draws; meta[5] = cfg.bicubic_gt_downsampling)
     cases = [("c1_same", 6, 1, 16, 16, False), ("c1_resize", 4, 1, 16, 24, False), ("c2_x2", 8, 2, 16, 32, False),
-             ("c3_ratio", 12, 3, 12, 31, True), ("c4_valid", 16, 4, 8, 8, True)]
-    for name, B, C, D, S, var in cases:
+             ("c3_ratio", 12, 3, 12, 31, True), ("c4_valid", 16, 4, 8, 8, True),
+             ("c1_bicubic", 4, 1, 16, 24, False, True), ("c2_bicubic_x2", 8, 2, 16, 32, False, True)]
+    for name, B, C, D, S, var, *bic in cases:
+        bic = bool(bic and bic[0])
         G = B // C
         pred = rng.uniform(0, 1, (B, D, D, 1)).astype(np.float32)
         gt = (rng.uniform(0, 1, (G, S, S, 1)) > 0.5).astype(np.float32)
         valid = rng.integers(0, 2, (G,)).astype(np.float32) if var else np.ones((G,), np.float32)
         if var:
             valid[0] = 1.0
-        cfg = make_cfg(pose_predict_num_candidates=C, variable_num_views=var, vox_size=D)
-        out[name + "_meta"] = np.array([B, C, D, S, int(var)])
+        cfg = make_cfg(pose_predict_num_candidates=C, variable_num_views=var, vox_size=D, bicubic_gt_downsampling=bic)
+        out[name + "_meta"] = np.array([B, C, D, S, int(var)] + ([1] if bic else []))
         out[name + "_pred"], out[name + "_gt"], out[name + "_valid"] = pred, gt, valid
         for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
             tf.set_float_dtype(dt)
@@ -102,7 +105,8 @@ def loss_cases():
             if C > 1:
                 g_in = inputs["masks"]
                 if S > D:
-                    g_in = tf.image.resize_images(g_in, [D, D], tf.image.ResizeMethod.BILINEAR)
+                    g_in = tf.image.resize_images(g_in, [D, D], tf.image.ResizeMethod.BICUBIC if bic
+                                                  else tf.image.ResizeMethod.BILINEAR)
                 _, win = model.proj_loss_pose_candidates(g_in, outputs["projs"], inputs)
                 out[name + "_winners"] = np.asarray(win.detach().numpy(), dtype=np.int64)
             loss = model.add_proj_loss(inputs, outputs, 1.0, add_summary=False)

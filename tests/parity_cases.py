@@ -204,7 +204,9 @@ def rgb_case_matches_goldens(dev, name):
         assert relerr(gr[k], g[k + "_f64"]) < TOL_GRAD, k
 
 
-LOSS_CASES = ["c1_same", "c1_resize", "c2_x2", "c3_ratio", "c4_valid"]
+# (the *_bicubic cases: cfg.bicubic_gt_downsampling -- the resize is a restatement of TF's ResizeBicubic on both sides
+# of the comparison, see util/losses.resize_images_bicubic_tf1: parity unpinned for that branch)
+LOSS_CASES = ["c1_same", "c1_resize", "c2_x2", "c3_ratio", "c4_valid", "c1_bicubic", "c2_bicubic_x2"]
 
 
 def silhouette_loss_matches_reference(dev, name):
@@ -214,9 +216,9 @@ def silhouette_loss_matches_reference(dev, name):
     from dpc_amd import model_pc as M
     from helpers import load
     g = load("caller_loss")
-    B, C, D, S, var = (int(v) for v in g[name + "_meta"])
+    B, C, D, S, var = (int(v) for v in g[name + "_meta"][:5])
     cfg = dpc_amd.default_config(vox_size=D, pose_predict_num_candidates=C, variable_num_views=bool(var),
-                                 pose_predictor_student=False)
+                                 pose_predictor_student=False, bicubic_gt_downsampling=len(g[name + "_meta"]) > 5)
     model = M.ModelPointCloud(cfg, global_step=0, device=dev)
     pred = torch.tensor(g[name + "_pred"], device=dev, requires_grad=True)
     inputs = {"masks": torch.tensor(g[name + "_gt"], device=dev),

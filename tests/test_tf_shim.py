@@ -141,6 +141,46 @@ def test_resize_images_bilinear_legacy(which):
         assert np.allclose(got, expect, rtol=2e-7, atol=1e-6), (size, got, expect)   # fp32 interpolation arithmetic
 
 
+def _bicubic_fns():
+    import dpc_amd  # noqa: F401
+    from dpc_amd.util.losses import resize_images_bicubic_tf1
+    shim = lambda im, size: _np(tf.image.resize_images(tf.constant(im), list(size), tf.image.ResizeMethod.BICUBIC))
+    prod = lambda im, size: resize_images_bicubic_tf1(torch.tensor(im), list(size)).numpy()
+    return shim, prod
+
+
+def test_resize_images_bicubic_legacy_closed_forms():
+    """tf.image.resize_images(..., BICUBIC) (r1.x ResizeBicubic, align_corners=False, A = -0.75 table; no TF binary here:
+    the restatements are pinned to what the published op implies in closed form).  (1) the four weights sum to one:
+    a constant image stays constant; (2) an integer scale lands on table entry 0 = weights (0, 1, 0, 0): out[y, x] =
+    in[s y, s x] EXACTLY; (3) scale 0.5 (upsampling 2x) at odd outputs: fraction 1/2 -> table entry 512 -> the classic
+    (-3, 19, 19, -3) / 32 taps of the A = -0.75 kernel, with the neighbours clamped at the border."""
+    rng = np.random.default_rng(5)
+    for fn in _bicubic_fns():
+        const = np.full((2, 9, 9, 1), 0.37, np.float32)
+        assert np.allclose(fn(const, (4, 4)), 0.37, atol=2e-7)
+        im = rng.random((2, 8, 12, 3)).astype(np.float32)
+        assert np.array_equal(fn(im, (4, 4)), im[:, ::2, ::3])
+        row = rng.random((1, 1, 6, 1)).astype(np.float32)
+        up = fn(row, (1, 12))[0, 0, :, 0]
+        r = row[0, 0, :, 0]
+        assert np.array_equal(up[0::2], r)
+        idx = lambda k: r[min(max(k, 0), 5)]
+        mid = np.array([(-3 * idx(k - 1) + 19 * idx(k) + 19 * idx(k + 1) - 3 * idx(k + 2)) / 32 for k in range(6)], np.float32)
+        assert np.allclose(up[1::2], mid, rtol=0, atol=2e-7)
+
+
+@pytest.mark.parametrize("shape,size", [((2, 128, 128, 1), (64, 64)), ((1, 7, 10, 2), (5, 3)), ((1, 5, 5, 1), (5, 5)),
+                                        ((1, 96, 96, 1), (64, 64)), ((1, 4, 4, 1), (9, 7))])
+def test_resize_images_bicubic_product_equals_the_loop_restatement(shape, size):
+    """the vectorised torch version the loss path calls against the pixel-by-pixel loop of the shim"""
+    shim, prod = _bicubic_fns()
+    im = np.random.default_rng(sum(shape)).random(shape).astype(np.float32)
+    a, b = shim(im, size), prod(im, size)
+    assert a.shape == b.shape == (shape[0], size[0], size[1], shape[3])
+    assert np.abs(a - b).max() <= 2e-7
+
+
 def test_augmented_assignment_rebinds_like_tf():
     """TF tensors are immutable: `q /= n`, `x += t` build new tensors and leave the operands untouched
     (quaternion.py:106, point_cloud.py:179-213 rely on it)."""
