@@ -329,3 +329,43 @@ def test_fused_width_rule():
     fused = lambda D: bool(lib.dpc_saved_layout(ctypes.byref(dpc_amd._capi.DpcShape(2, 100, 32, D, 5, 5, 5)), ctypes.byref(P)) & 2)
     assert all(fused(D) for D in (20, 24, 28, 32, 40, 48, 56, 64, 72, 80, 96, 112, 128, 144, 160, 192, 240, 256))
     assert not any(fused(D) for D in (16, 18, 30, 33, 50, 66, 100, 130, 136, 257, 260))
+
+
+def test_emu_view_walking_order_does_not_change_results(tmp_path):
+    """The launcher walks the views last-to-first in some kernels when a grid exceeds the Infinity Cache
+    (host_launch.inc: view_order): every order (DPC_VIEW_ORDER = 0 ... 15, read once per process) gives the same bits."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, hashlib
+os.environ["DPC_TEST_HOOKS"] = "1"
+import numpy as np, torch
+sys.path.insert(0, %r)
+import dpc_amd
+emu = dpc_amd._capi.DpcLibrary(os.path.join(%r, "tests", "hipemu", "libdpc_emu.so"), host_memory=True)
+dpc_amd._capi.set_library(emu)
+rng = np.random.default_rng(4)
+B, N, D, K = 5, 300, 32, 5
+cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K)
+pc = torch.tensor((rng.normal(size=(B, N, 3)) * 0.15).astype(np.float32), requires_grad=True)
+pose = torch.tensor(rng.normal(size=(B, 4)).astype(np.float32), requires_grad=True)
+scale = torch.tensor(rng.uniform(0.5, 1.0, (B, 1)).astype(np.float32), requires_grad=True)
+out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, dpc_amd.smoothing_kernel(cfg, 0.9, device="cpu"), scaling_factor=scale)
+w = torch.tensor(rng.standard_normal((B, D, D, 1)).astype(np.float32))
+g = torch.autograd.grad((out["proj"] * w).sum(), [pc, scale])
+h = hashlib.sha256()
+for t in (out["proj"], out["proj_depth"], g[0]):
+    h.update(t.detach().numpy().tobytes())
+print("HASH", h.hexdigest(), float(g[1].sum()))
+''' % (ROOT, ROOT)
+    res = {}
+    for order in ("0", "5", "15"):
+        env = dict(os.environ, DPC_VIEW_ORDER=order)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("HASH")][0].split()
+        res[order] = (line[1], float(line[2]))
+    assert res["0"][0] == res["5"][0] == res["15"][0], res
+    assert abs(res["0"][1] - res["15"][1]) <= 1e-5 * max(1.0, abs(res["0"][1]))      # (dscale: per-work-group partials, same order)
