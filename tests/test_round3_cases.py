@@ -8,6 +8,17 @@ import parity_cases
 from helpers import synth
 
 
+_RANKS = {}
+
+
+def _ranks_of_10240_keys(N):
+    """the permutation's ranks for 32 seeds x 320 instances (they do not depend on `keep`: computed once for both cases)"""
+    from oracle import dropout_ref
+    if N not in _RANKS:
+        _RANKS[N] = np.stack([dropout_ref.dropout_rank(N, seed, b) for seed in range(1000, 1032) for b in range(320)])
+    return _RANKS[N]
+
+
 @pytest.mark.parametrize("keep", [560, 4000])      # pc_point_dropout 0.07 and 0.5 of 8000 points
 def test_dropout_permutation_statistics(keep):
     """dpc/util/point_cloud.py:293-319 draws int(N keep_prob) of N points uniformly without replacement,
@@ -15,10 +26,8 @@ def test_dropout_permutation_statistics(keep):
     the same to first and second order: every point is kept with probability keep/N, every pair with
     keep (keep-1) / (N (N-1)) -- chi-squares over 10 240 keys (32 seeds x 320 instances) within 5 sigma, no
     single z-score beyond 6."""
-    from oracle import dropout_ref
     N = 8000
-    masks = np.stack([dropout_ref.dropout_rank(N, seed, b) < np.uint64(keep) for seed in range(1000, 1032)
-                      for b in range(320)])
+    masks = _ranks_of_10240_keys(N) < np.uint64(keep)
     st = parity_cases.dropout_statistics(masks, keep, parity_cases.dropout_pairs(N, np.random.default_rng(7)))
     parity_cases.assert_dropout_statistics(st)
     # neighbouring instances and neighbouring seeds overlap like independent draws: mean |A & B| = keep^2 / N

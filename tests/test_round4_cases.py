@@ -361,11 +361,11 @@ for t in (out["proj"], out["proj_depth"], g[0]):
 print("HASH", h.hexdigest(), float(g[1].sum()))
 ''' % (ROOT, ROOT)
     res = {}
-    for order in ("0", "5", "15"):
+    for order in ("0", "15"):
         env = dict(os.environ, DPC_VIEW_ORDER=order)
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-2000:]
         line = [l for l in p.stdout.splitlines() if l.startswith("HASH")][0].split()
         res[order] = (line[1], float(line[2]))
-    assert res["0"][0] == res["5"][0] == res["15"][0], res
+    assert res["0"][0] == res["15"][0], res
     assert abs(res["0"][1] - res["15"][1]) <= 1e-5 * max(1.0, abs(res["0"][1]))      # (dscale: per-work-group partials, same order)
