@@ -24,6 +24,21 @@ def pytest_configure(config):
         subprocess.check_call(["make", "-s", "-j8", "-C", os.path.dirname(lib)])
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _variant_gpu_library():
+    """kernel experiments: DPC_GPU_LIB=<csrc/libdpc_x.so> runs the -m gpu tests against a variant build of the HIP library
+    (through the ctypes binding: the compiled one opens the shipped file)."""
+    path = os.environ.get("DPC_GPU_LIB")
+    if not path:
+        yield
+        return
+    os.environ["DPC_BINDING"] = "ctypes"
+    import dpc_amd
+    prev = dpc_amd._capi.set_library(dpc_amd._capi.DpcLibrary(os.path.abspath(path)))
+    yield
+    dpc_amd._capi.set_library(prev)
+
+
 def pytest_collection_modifyitems(config, items):
     try:
         import torch
@@ -46,7 +61,9 @@ def emu_library():
     emu_dir = os.path.join(ROOT, "tests", "hipemu")
     subprocess.check_call(["make", "-s", "-j8", "-C", emu_dir])
     import dpc_amd
-    return dpc_amd._capi.DpcLibrary(os.path.join(emu_dir, "libdpc_emu.so"), host_memory=True)
+    # (kernel experiments: DPC_EMU_LIB names a variant built with `make -C tests/hipemu OUT=... EXTRA=-D...`)
+    name = os.environ.get("DPC_EMU_LIB", "libdpc_emu.so")
+    return dpc_amd._capi.DpcLibrary(os.path.join(emu_dir, name), host_memory=True)
 
 
 @pytest.fixture()

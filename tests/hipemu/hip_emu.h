@@ -99,6 +99,7 @@ static inline float atomicAdd(float* p, float v) {
 
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 
 // wave64 shuffles / votes through the exchange buffer; they rendezvous per WAVE, so
 // they may sit in wave-uniform (not necessarily block-uniform) control flow, as on the GPU
