@@ -181,6 +181,25 @@ def test_resize_images_bicubic_product_equals_the_loop_restatement(shape, size):
     assert np.abs(a - b).max() <= 2e-7
 
 
+def test_resize_images_bicubic_properties():
+    """Property (hypothesis): for any input / output size the four taps sum to one (constants stay constant to fp32 rounding),
+    the loop restatement and the vectorised product version agree, and an output the same size as the input is the input."""
+    from hypothesis import given, settings, strategies as st
+    shim, prod = _bicubic_fns()
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 9), st.integers(1, 9), st.integers(1, 9), st.integers(1, 9), st.integers(0, 2 ** 31 - 1))
+    def check(ih, iw, oh, ow, seed):
+        im = np.random.default_rng(seed).random((1, ih, iw, 2)).astype(np.float32)
+        a, b = shim(im, (oh, ow)), prod(im, (oh, ow))
+        assert a.shape == b.shape == (1, oh, ow, 2) and np.abs(a - b).max() <= 3e-7
+        c = prod(np.full((1, ih, iw, 1), 0.625, np.float32), (oh, ow))
+        assert np.abs(c - 0.625).max() <= 3e-7
+        if (oh, ow) == (ih, iw):
+            assert np.array_equal(b, im)
+    check()
+
+
 def test_augmented_assignment_rebinds_like_tf():
     """TF tensors are immutable: `q /= n`, `x += t` build new tensors and leave the operands untouched
     (quaternion.py:106, point_cloud.py:179-213 rely on it)."""
