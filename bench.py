@@ -100,11 +100,12 @@ def build_train_case(args, device, rank, world):
     torch.manual_seed(0)
     net = Im2PointCloud(cfg, image, **net_kw).to(device)
     model, buckets = net, None
-    if world > 1 and args.graph:
+    dist_on = dpc_amd.distributed.active()     # several ranks, or one rank under --force-dist
+    if dist_on and args.graph:
         # a recorded step cannot hold DDP's reducer (host-side bucket bookkeeping between steps): the same bucketed,
         # backward-overlapped all-reduce is issued by gradient hooks instead (dpc_amd.distributed.GradBuckets)
         buckets = dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=64)
-    elif world > 1:
+    elif dist_on:
         ddp_kw = dict(device_ids=[device.index]) if device.type == "cuda" else {}
         model = torch.nn.parallel.DistributedDataParallel(net, bucket_cap_mb=64, gradient_as_bucket_view=True, **ddp_kw)
     projector = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device=device)
@@ -121,7 +122,7 @@ def build_train_case(args, device, rank, world):
     case = dict(B=views, N=int(cfg.pc_num_points * args.keep_prob), D=cfg.vox_size, K=cfg.pc_gauss_kernel_size,
                 sigma=cfg.pc_relative_sigma, models=models, params=sum(p.numel() for p in net.parameters()),
                 views_per_model=cfg.step_size, candidates=cfg.pose_predict_num_candidates,
-                reducer="GradBuckets" if buckets is not None else ("DDP" if world > 1 else None), projector=projector,
+                reducer="GradBuckets" if buckets is not None else ("DDP" if dist_on else None), projector=projector,
                 run=lambda: ts.train_step(model, projector, inputs, opt, world, buckets=buckets))
     return case
 
@@ -391,6 +392,11 @@ def main():
                     help="seconds of untimed steps BEFORE the --warmup steps: the GPU's clocks take ~0.1 s of continuous load to "
                          "settle after the idle set-up phase (profiles/r03/startup_probe.txt); without it a 20-step timed block "
                          "runs 4-8 %% below the steady state the `timing` blocks see.  0 = off.  Reported in config.burn_in_s")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: create the process group anyway (backend nccl = RCCL, ONE rank) and take the "
+                         "distributed code path -- RCCL communicator + watchdog, barriers and the MAX all-reduce through "
+                         "ProcessGroupNCCL, --config 3: DDP's reducer, --config 3 --graph: GradBuckets' bucket all-reduces "
+                         "recorded into the HIP graph.  The one-GPU rehearsal of the 2/4/8-GPU runs (no bytes cross xGMI)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -398,6 +404,15 @@ def main():
     dd = dpc_amd.distributed
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    if args.force_dist or os.environ.get("DPC_FORCE_DIST") == "1":
+        args.force_dist = True
+        os.environ["DPC_FORCE_DIST"] = "1"
+        if "WORLD_SIZE" not in os.environ:            # a one-rank "launch": what torch.distributed.run would export
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     rank, _, world = dd.env_world()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -451,7 +466,8 @@ def main():
         case = build_case(args.config, batch, device, seed_offset=1000 * rank, kind=args.points, N=args.num_points,
                           sigma=args.sigma, K=args.k, D=args.vox)
         run = lambda: step(case)
-    numa_note = dd.bind_to_gpu_numa(device) if (world > 1 and not DRY_RUN) else None
+    dist_on = dd.active()       # a process group exists (several ranks, or --force-dist): the distributed code path
+    numa_note = dd.bind_to_gpu_numa(device) if (dist_on and not DRY_RUN) else None
     graph_note = None
     if args.graph and train and DRY_RUN:
         args.graph, graph_note = False, "dry run: the recordable reducer (GradBuckets) runs eagerly under gloo"
@@ -462,7 +478,7 @@ def main():
         # recorded into ONE hipGraph per rank and replayed (dpc_amd.graphs.RecordedStep: the shared recipe -- warm-up
         # count, barrier before the capture, thread-local capture mode, re-record when the blur's tap count moves).
         try:
-            recorded = dpc_amd.graphs.RecordedStep(case["run"], world=world, device=device,
+            recorded = dpc_amd.graphs.RecordedStep(case["run"], world=world, device=device, collectives=dist_on,
                                                    key=case["projector"].effective_tap_counts)
             run = recorded
         except Exception as e:                       # noqa: BLE001
@@ -488,7 +504,7 @@ def main():
             sys.stderr.write("[rank %d] %s\n" % (rank, graph_note))
             run = lambda: step(case)
     if args.burn_in > 0 and not DRY_RUN:       # clocks up (see --burn-in); untimed, before the contract's warm-up steps
-        if train and world > 1:
+        if train and dist_on:
             # every step holds collectives: all ranks must run the SAME number of steps -- a count, not a clock
             for _ in range(max(8, int(args.burn_in / 0.004))):
                 run()
@@ -526,7 +542,7 @@ def main():
         e1.record()
         e1.synchronize()
         blocks.append(e0.elapsed_time(e1) / args.steps)
-    if world > 1:
+    if dist_on:
         dd.barrier(device)
 
     # ---- per-kernel durations (HIP events on the launch stream), rank 0 ----------
@@ -617,7 +633,7 @@ def main():
                         "PyTorch; HIP projector + silhouette-loss epilogue; Adam), %d models x %d views x %d pose "
                         "candidates = %d views per GPU of N=%d pts -> %d^3, K=%d, sigma=%.1f, %.1f M parameters%s"
                         % (cfg_idx, case["models"], case["views_per_model"], case["candidates"], case["B"], case["N"], case["D"], case["K"], case["sigma"],
-                           case["params"] / 1e6, ", DDP (RCCL all-reduce)" if world > 1 else ""))
+                           case["params"] / 1e6, ", %s (RCCL all-reduce)" % case["reducer"] if case.get("reducer") else ""))
         else:
             workload = ("BASELINE.json configs[%d]%s: pointcloud_project_fast fwd+bwd, N=%d, grid %d^3, K=%d, sigma=%.1f, "
                         "batch %d views per GPU, %s point clouds, dproj=(proj-gt)/B"
@@ -637,10 +653,12 @@ def main():
                        "hip_graph": bool(args.graph), **({"hip_graph_note": graph_note} if graph_note else {}),
                        "burn_in_s": 0.0 if DRY_RUN else args.burn_in,
                        "training_step": bool(train),
-                       "parallelism": (("models sharded x%d (%s), gradient all-reduce over RCCL" % (world, case.get("reducer") or "DDP")) if train else
+                       "parallelism": ((("models sharded x%d (%s), gradient all-reduce over RCCL" % (world, case["reducer"]))
+                                        if case.get("reducer") else "one process, no reducer") if train else
                                        ("views sharded x%d, no data-path collective" % world))
-                                      + ("" if world == 1 else " [%s%s]" % (dd.collective_library() or "no process group",
-                                                                             "; rank 0: " + numa_note if numa_note else ""))},
+                                      + ("" if not dist_on else " [%s%s%s]" % (dd.collective_library() or "no process group",
+                                                                              ", forced one-rank group" if args.force_dist and world == 1 else "",
+                                                                              "; rank 0: " + numa_note if numa_note else ""))},
             "timing": None if not blocks else {
                 "repeats": len(blocks), "steps_per_block": args.steps, "clock": "HIP events, rank 0",
                 "ms_per_step_median": pctl(blocks, 50), "ms_per_step_p10": pctl(blocks, 10),

@@ -19,17 +19,29 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend=None, device=None):
+def active():
+    """True iff a process group exists: the distributed machinery (barriers, reducers, the bench line's `parallelism`
+    note) keys on THIS, not on world > 1 -- a forced one-rank group (below) runs the same code as eight ranks."""
+    return dist.is_available() and dist.is_initialized()
+
+
+def init(backend=None, device=None, force=None):
     """Initialise torch.distributed from the torchrun environment.  Returns
-    (rank, world, device).  A single process needs no process group."""
+    (rank, world, device).  A single process needs no process group -- unless `force` (default: DPC_FORCE_DIST=1 in
+    the environment; `bench.py --force-dist`) asks for one: a ONE-rank group under backend "nccl" creates a real RCCL
+    communicator on the device, runs its watchdog thread, and sends every barrier / all-reduce / DDP bucket /
+    GradBuckets collective through ProcessGroupNCCL on its own stream -- the whole multi-GPU code path on a one-GPU
+    box (what it cannot show is bytes over xGMI)."""
     rank, local_rank, world = env_world()
+    if force is None:
+        force = os.environ.get("DPC_FORCE_DIST") == "1"
     if device is None:
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
             device = torch.device("cuda", local_rank)
         else:
             device = torch.device("cpu")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -144,9 +156,12 @@ class GradBuckets(object):
         loss.backward(); buckets.finish()                          # per step: grads are now the rank AVERAGE
         optimizer.step(); buckets.zero_()                          # (never set_to_none: the views must survive)
 
-    Averaging matches DDP: sum over ranks, divided by the world size.  Works with any backend (the gloo tests
-    check it against a single process on the concatenated batch); with one rank it degenerates to plain
-    accumulation into the flat buffers.
+    Averaging matches DDP: sum over ranks, divided by the world size.  Under RCCL the division rides inside the
+    collective (ReduceOp.AVG: RCCL pre-multiplies by 1 / world as it reduces -- no second pass over the 133 MB of
+    buckets); other backends (gloo has no AVG) sum and divide afterwards.  Works with any backend (the gloo tests
+    check it against a single process on the concatenated batch); without a process group it degenerates to plain
+    accumulation into the flat buffers.  A ONE-rank process group (distributed.init(force=True)) still issues every
+    collective: that is the point of it -- the same calls, streams and graph edges as with eight ranks.
 
     Invariants, checked (a violation would otherwise let the ranks diverge silently):
     * every p.grad must still BE its bucket view when finish() runs -- optimizer.zero_grad() (set_to_none=True by
@@ -161,7 +176,10 @@ class GradBuckets(object):
 
     def __init__(self, params, bucket_mb=64, process_group=None):
         self.group = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.reduce = active()              # a process group exists (possibly of ONE rank): the collectives are issued
+        self.world = dist.get_world_size(process_group) if self.reduce else 1
+        self.in_collective_average = (self.reduce and dist.get_backend(process_group) == "nccl"
+                                      and os.environ.get("DPC_BUCKET_AVG", "1") == "1")
         params = [p for p in params if p.requires_grad]
         limit = int(bucket_mb * (1 << 20))
         # buckets in REVERSE parameter order: the backward pass produces the last layers' gradients first
@@ -204,8 +222,9 @@ class GradBuckets(object):
     def _issue_ready(self, force=False):
         """issue, in bucket order, the all-reduce of every leading bucket that is complete (force: of all that are left)"""
         while self._next < len(self.buckets) and (force or self._pending[self._next] == 0):
-            if self.world > 1:
-                self._works.append(dist.all_reduce(self.buckets[self._next][0], group=self.group, async_op=True))
+            if self.reduce:
+                op = dist.ReduceOp.AVG if self.in_collective_average else dist.ReduceOp.SUM
+                self._works.append(dist.all_reduce(self.buckets[self._next][0], op=op, group=self.group, async_op=True))
             self._next += 1
 
     def _hook(self, p):
@@ -225,11 +244,12 @@ class GradBuckets(object):
                                    "sets it to None by default -- use buckets.zero_(); backward(create_graph=True) replaces "
                                    "it): the buckets hold stale gradients")
         self._issue_ready(force=True)        # buckets with parameters that received no gradient this step: reduce anyway
-        if self.world > 1:
+        if self.reduce:
             for w in self._works:
                 w.wait()
-            for flat, _ in self.buckets:
-                flat.div_(self.world)
+            if not self.in_collective_average and self.world > 1:
+                for flat, _ in self.buckets:
+                    flat.div_(self.world)
         self._works = []
         self._arm()
 

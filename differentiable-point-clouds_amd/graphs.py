@@ -34,13 +34,16 @@ class RecordedStep(object):
     ``run`` takes no arguments and returns a tensor (or a tuple / None) that lives in the graph's memory pool --
     read it after the replay, before the next one."""
 
-    def __init__(self, run, world=1, device=None, key=None, warmup=None):
+    def __init__(self, run, world=1, device=None, key=None, warmup=None, collectives=None):
         self._run, self._key = run, key
         self.world = int(world)
+        # does the step hold collectives?  (default: with several ranks; a forced ONE-rank process group -- the
+        # one-GPU rehearsal of the multi-GPU path -- says so explicitly and gets the same warm-up and barrier)
+        self.collectives = (self.world > 1) if collectives is None else bool(collectives)
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.records = 0                    # how many times the step has been recorded (1 + re-records)
         self.graph, self.out = None, None
-        self._warm(3 if self.world == 1 else 11) if warmup is None else self._warm(int(warmup))
+        self._warm(11 if self.collectives else 3) if warmup is None else self._warm(int(warmup))
         self._record()
 
     def _warm(self, n):
@@ -54,7 +57,7 @@ class RecordedStep(object):
     def _record(self):
         torch.cuda.synchronize(self.device)          # nothing of the previous recording is in flight any more ...
         self.graph, self.out = None, None            # ... before its memory pool is released
-        if self.world > 1:
+        if self.collectives:
             dd.barrier(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):

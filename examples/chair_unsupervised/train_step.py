@@ -102,9 +102,10 @@ def main():
     torch.manual_seed(0)
     net = Im2PointCloud(cfg, args.image_size).to(device)
     model, buckets = net, None
-    if world > 1 and args.graph:
+    dist_on = dd.active()          # several ranks, or a forced one-rank group (DPC_FORCE_DIST=1: the one-GPU rehearsal)
+    if dist_on and args.graph:
         buckets = dd.GradBuckets(net.parameters(), bucket_mb=64)       # recordable bucketed all-reduce (no DDP wrapper)
-    elif world > 1:
+    elif dist_on:
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[device.index], bucket_cap_mb=64,
                                                           gradient_as_bucket_view=True)
     projector = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device=device)
@@ -117,7 +118,8 @@ def main():
         # over the first collectives), barrier, thread-local capture (the RCCL watchdog polls events meanwhile), and a
         # new recording whenever the annealed blur moves on to a smaller tap count
         projector.enable_graph_replay(follow_tap_counts=True)
-        run = dpc_amd.graphs.RecordedStep(run, world=world, device=device, key=projector.effective_tap_counts)
+        run = dpc_amd.graphs.RecordedStep(run, world=world, device=device, collectives=dist_on,
+                                             key=projector.effective_tap_counts)
     step = 0
     for _ in range(args.warmup):
         projector.set_global_step(step)          # sigma / dropout schedules (in place under --graph)

@@ -99,3 +99,31 @@ def test_value_is_global_views_over_the_slowest_ranks_time(emu_library):
     assert views == 2 * 2
     assert abs(j["value"] - views / (j["ms_per_step"] * 1e-3)) <= 1e-9 * j["value"]
     assert "backend gloo, world 2" in j["config"]["parallelism"]
+
+
+def test_force_dist_takes_the_distributed_path_with_one_rank(emu_library):
+    """`bench.py --gpus 1 --force-dist`: a ONE-rank process group (here gloo; on a GPU box backend nccl = RCCL) and the
+    distributed code path -- barriers and the MAX all-reduce go through the group, the line says what the rank saw."""
+    r = _run(["--steps", "2", "--warmup", "1", "--force-dist"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 1 and j["config"]["global_batch"] == 2
+    assert "backend gloo, world 1" in j["config"]["parallelism"] and "forced one-rank group" in j["config"]["parallelism"]
+
+
+def test_force_dist_training_step_runs_ddp_and_the_recordable_reducer(emu_library):
+    """--config 3 under a forced one-rank group: the eager step is wrapped in DistributedDataParallel, --graph uses
+    GradBuckets (whose bucket all-reduces are then issued although the world is 1)."""
+    r = _run(["--config", "3", "--steps", "2", "--warmup", "1", "--force-dist"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 1 and "(DDP)" in j["config"]["parallelism"] and "world 1" in j["config"]["parallelism"]
+    assert "configs[2]" in j["config"]["workload"] and "DDP (RCCL all-reduce)" in j["config"]["workload"]
+    r = _run(["--config", "3", "--graph", "--steps", "2", "--warmup", "1"], {"DPC_FORCE_DIST": "1"})   # the env form
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert "(GradBuckets)" in j["config"]["parallelism"] and "forced one-rank group" in j["config"]["parallelism"]
+    # and without it a single process has no reducer at all
+    r = _run(["--config", "3", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "one process, no reducer" == _json_line(r.stdout)["config"]["parallelism"]

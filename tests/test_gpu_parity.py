@@ -731,6 +731,95 @@ dpc_amd.distributed.finalize()
     assert "WORST" in r.stdout
 
 
+# ---- RCCL on the one GPU this tier has: a forced ONE-rank process group (backend nccl).  What it exercises is first
+# contact -- communicator creation on the device, the watchdog thread beside a HIP-graph capture, ProcessGroupNCCL's
+# stream fork / join as graph edges, RCCL's kernel for the in-collective average, DDP's reducer -- not bytes over xGMI.
+
+def test_bench_one_rank_rccl_projector():
+    """`bench.py --gpus 1 --force-dist`: barriers and the MAX all-reduce of the step time through RCCL, the projector's
+    step recorded into a HIP graph while the RCCL watchdog thread is alive."""
+    j = _bench_multi_gpu(["--gpus", "1", "--force-dist", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
+    par = j["config"]["parallelism"]
+    assert j["n_gpus"] == 1 and j["config"]["global_batch"] == 32 and j["value"] > 0 and j["config"]["hip_graph"] is True
+    assert "backend nccl, world 1, RCCL " in par and "forced one-rank group" in par, par
+
+
+def test_bench_one_rank_rccl_training_step_ddp_and_recorded():
+    """The training step under RCCL with one rank: eager under DistributedDataParallel (its reducer's bucket
+    all-reduces), and --graph: GradBuckets' bucket all-reduces (ReduceOp.AVG -- an RCCL kernel even with one rank)
+    recorded into the HIP graph beside the live watchdog; the capture must not fall back."""
+    e = _bench_multi_gpu(["--gpus", "1", "--force-dist", "--config", "3", "--steps", "5", "--warmup", "3", "--batch", "4",
+                          "--no-cpu-baseline"])
+    assert e["config"]["training_step"] and "(DDP)" in e["config"]["parallelism"] and e["value"] > 0
+    assert "backend nccl, world 1, RCCL " in e["config"]["parallelism"]
+    g = _bench_multi_gpu(["--gpus", "1", "--force-dist", "--config", "3", "--steps", "5", "--warmup", "3", "--batch", "4",
+                          "--graph", "--no-cpu-baseline"])
+    assert "(GradBuckets)" in g["config"]["parallelism"] and "backend nccl, world 1, RCCL " in g["config"]["parallelism"]
+    assert g["config"]["hip_graph"] is True, g["config"].get("hip_graph_note")
+    assert g["value"] > 0
+
+
+def test_grad_buckets_equal_ddp_equal_plain_under_one_rank_rccl():
+    """One rank, backend nccl: GradBuckets (AVG inside the collective), DistributedDataParallel and the plain
+    single-process backward give the same gradients; the recorded GradBuckets step replays to the same values; and RCCL
+    really ran (a collective on a fresh tensor changes it as the op says)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "examples", "chair_unsupervised"))
+import dpc_amd, train_step as ts
+from nets import Im2PointCloud
+rank, world, dev = dpc_amd.distributed.init("nccl", force=True)
+assert dpc_amd.distributed.active() and world == 1 and dist.get_backend() == "nccl"
+print("LIB", dpc_amd.distributed.collective_library())
+# RCCL itself: AVG = pre-multiplied sum (a kernel even with one rank), all_gather = a device copy, broadcast, barrier
+t = torch.arange(1024, device=dev, dtype=torch.float32)
+dist.all_reduce(t, op=dist.ReduceOp.AVG); dist.all_reduce(t, op=dist.ReduceOp.SUM)
+out = torch.empty(1024, device=dev); dist.all_gather_into_tensor(out, t); dist.broadcast(out, 0); dist.barrier()
+assert torch.equal(out, torch.arange(1024, device=dev, dtype=torch.float32))
+cfg = ts.make_cfg(batch_size=2, pc_point_dropout=1.0)
+inputs = ts.synthetic_batch(cfg, dev, 128, seed=0)
+grads = {}
+for mode in ("plain", "ddp", "buckets"):
+    torch.manual_seed(0)
+    net = Im2PointCloud(cfg, 128).to(dev)
+    model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index]) if mode == "ddp" else net
+    red = dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=16) if mode == "buckets" else None
+    assert red is None or (red.reduce and red.in_collective_average and len(red.buckets) > 1)
+    proj = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device=dev)
+    def run():
+        o = proj.compute_projection(inputs, proj.replicate_outputs(model(inputs["images"])), is_training=False)
+        proj.add_proj_loss(inputs, o, 1.0).backward()
+        if red is not None:
+            red.finish()
+    run()
+    grads[mode] = [p.grad.clone() for p in net.parameters()]
+    if mode == "buckets":          # the same step recorded (collectives inside the graph) and replayed twice
+        red.zero_()
+        step = dpc_amd.graphs.RecordedStep(lambda: (red.zero_(), run())[1], world=1, device=dev, collectives=True)
+        step(); step()
+        torch.cuda.synchronize()
+        grads["replayed"] = [p.grad.clone() for p in net.parameters()]
+ref = grads["plain"]
+for mode in ("ddp", "buckets", "replayed"):
+    worst = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-12)) for a, b in zip(grads[mode], ref))
+    print("WORST", mode, worst)
+    assert worst < 1e-5, (mode, worst)
+dpc_amd.distributed.finalize()
+print("DONE")
+""" % (root, root)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DPC_POISON_BUFFERS")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29633")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "DONE" in r.stdout and "backend nccl, world 1, RCCL " in r.stdout, r.stdout
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(C=1, with_valid=False), dict(B=12, C=2, S=32, rep=3),
                                 dict(B=320, C=4, N=8000, D=64, K=21, S=128, rep=20),          # the training step's shape
                                 dict(B=32, C=4, N=4000, D=128, K=11, S=128)])
