@@ -60,6 +60,16 @@ DRY_RUN = os.environ.get("DPC_BENCH_DRY_RUN") == "1"   # tests only: CPU emulati
 dpc_amd.synthetic.CONFIGS.setdefault(3, dict(B=320, N=8000, D=64, K=21, sigma=3.0))
 
 
+_T0 = time.perf_counter()
+
+
+def trace(msg):
+    """progress marks on stderr (DPC_BENCH_TRACE=1): where a run was when something outside Python's reach ended it"""
+    if os.environ.get("DPC_BENCH_TRACE") == "1":
+        sys.stderr.write("[bench +%.2fs] %s\n" % (time.perf_counter() - _T0, msg))
+        sys.stderr.flush()
+
+
 def build_case(cfg_id, B, device, seed_offset=0, kind="shell", N=None, sigma=None, K=None, D=None):
     over = {k: v for k, v in (("N", N), ("sigma", sigma), ("K", K), ("D", D)) if v is not None}
     if over:
@@ -466,6 +476,7 @@ def main():
         case = build_case(args.config, batch, device, seed_offset=1000 * rank, kind=args.points, N=args.num_points,
                           sigma=args.sigma, K=args.k, D=args.vox)
         run = lambda: step(case)
+    trace("case built")
     dist_on = dd.active()       # a process group exists (several ranks, or --force-dist): the distributed code path
     numa_note = dd.bind_to_gpu_numa(device) if (dist_on and not DRY_RUN) else None
     graph_note = None
@@ -503,6 +514,7 @@ def main():
             args.graph, graph_note = False, "HIP graph capture failed (%s: %s); eager launches" % (type(e).__name__, e)
             sys.stderr.write("[rank %d] %s\n" % (rank, graph_note))
             run = lambda: step(case)
+    trace("step recorded" if args.graph else "eager step")
     if args.burn_in > 0 and not DRY_RUN:       # clocks up (see --burn-in); untimed, before the contract's warm-up steps
         if train and dist_on:
             # every step holds collectives: all ranks must run the SAME number of steps -- a count, not a clock
@@ -519,15 +531,18 @@ def main():
         # test hook (dry run only): the last rank is slower by that many seconds per step -- the reported time must be ITS
         nap, fast = float(os.environ["DPC_BENCH_TEST_SLEEP_LAST_RANK"]), run
         run = lambda: (time.sleep(nap), fast())[1]
+    trace("burn-in done")
     for _ in range(args.warmup):
         run()
     dd.barrier(device)                      # barrier + torch.cuda.synchronize() on both sides
+    trace("warm-up done, timing")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
     dd.barrier(device)
     elapsed = dd.max_over_ranks(time.perf_counter() - t0, device)
     ms_step = elapsed / args.steps * 1e3
+    trace("timed region done: %.3f ms/step" % ms_step)
 
     # ---- spread: further blocks of `steps` steps, HIP events on the launch stream, every rank in step ----
     repeats = args.repeats
@@ -545,6 +560,7 @@ def main():
     if dist_on:
         dd.barrier(device)
 
+    trace("spread blocks done")
     # ---- per-kernel durations (HIP events on the launch stream), rank 0 ----------
     roof = None
     psteps = max(3, min(args.steps, 20))

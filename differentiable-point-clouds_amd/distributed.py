@@ -8,7 +8,10 @@ parameters, which is outside this path).
 
 backend "nccl" is RCCL on ROCm; CPU tests use "gloo".
 """
+import contextlib
 import os
+import sys
+import time
 
 import torch
 import torch.distributed as dist
@@ -47,8 +50,26 @@ def init(backend=None, device=None, force=None):
         if backend is None:
             backend = "nccl" if device.type == "cuda" else "gloo"
         kw = {"device_id": device} if device.type == "cuda" else {}
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        with _stdout_to_stderr():     # RCCL prints a version banner on STDOUT when its first communicator comes up;
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)      # stdout is for the ONE JSON line
+            if backend == "nccl":
+                dist.barrier()        # the communicator is created here at the latest
+                torch.cuda.synchronize(device)
     return rank, world, device
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """file-descriptor-level redirect (the banner comes from C code): fd 1 points at fd 2 inside the block"""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def bind_to_gpu_numa(device):
@@ -74,14 +95,28 @@ def bind_to_gpu_numa(device):
         cpus &= allowed
         if not cpus or cpus == allowed:
             return None
-        os.sched_setaffinity(0, cpus)
+        # sched_setaffinity(0) moves the CALLING thread only; the pools that already exist (OpenMP / ATen, the HIP
+        # runtime's and RCCL's helper threads) are moved one by one -- threads started later inherit the mask
+        moved = 0
+        try:
+            tids = [int(t) for t in os.listdir("/proc/self/task")]
+        except OSError:
+            tids = [0]
+        for tid in tids:
+            try:
+                os.sched_setaffinity(tid, cpus)
+                moved += 1
+            except OSError:              # a thread that exited meanwhile
+                pass
+        if moved == 0:
+            os.sched_setaffinity(0, cpus)
         node = "?"
         try:
             with open(base + "numa_node") as f:
                 node = f.read().strip()
         except OSError:
             pass
-        return "GPU %s -> NUMA node %s (%d CPUs)" % (bdf, node, len(cpus))
+        return "GPU %s -> NUMA node %s (%d CPUs, %d threads bound)" % (bdf, node, len(cpus), max(moved, 1))
     except Exception:  # noqa: BLE001 -- placement only affects speed
         return None
 
@@ -115,6 +150,29 @@ def barrier(device=None):
         torch.cuda.synchronize(device)
 
 
+def drain_watchdog(seconds=None):
+    """Give ProcessGroupNCCL's watchdog thread time to reap the works of the collectives issued so far; call it after a
+    synchronize and BEFORE starting a HIP-graph capture that will hold collectives.
+
+    Why (found on the first contact of this code with RCCL, round 5, profiles/r05/rccl_world1.txt): the watchdog polls
+    its list of outstanding works every 100 ms with hipEventQuery on each work's end event.  Those events were recorded
+    -- eagerly -- on the process group's communication stream.  A capture that contains a collective forks that very
+    stream into the capture, and HIP answers hipEventQuery with hipErrorCapturedEvent whenever the stream an event was
+    LAST RECORDED ON is capturing at the moment of the query (CUDA looks at the event itself), so a work that is
+    complete but not yet reaped -- the barrier right before the capture always is -- kills the process through the
+    watchdog's exception ("operation not permitted on an event last recorded in a capturing stream"), in about one run
+    in ten.  torch 2.10 no longer holds captures back until the watchdog's list is empty (the pending-event-query
+    counter of earlier releases is gone) and exposes no call that waits for it, so: everything issued so far has
+    completed (the caller synchronised), the next poll removes it, and two and a half poll periods are waited for here.
+    Works created DURING the capture are never handed to the watchdog (ProcessGroupNCCL checks the capture status)."""
+    if not active() or dist.get_backend() != "nccl":
+        return
+    if seconds is None:
+        seconds = float(os.environ.get("DPC_WATCHDOG_DRAIN_S", "0.25"))
+    if seconds > 0:
+        time.sleep(seconds)
+
+
 def max_over_ranks(value, device=None):
     """MAX all-reduce of a python float (the step time of the slowest rank)."""
     if not (dist.is_available() and dist.is_initialized()):
@@ -141,6 +199,9 @@ def finalize():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+_DIAG = os.environ.get("DPC_DIAG_HOOK") == "1"     # dev: say from which thread / stream every bucket collective is issued
 
 
 class GradBuckets(object):
@@ -195,6 +256,7 @@ class GradBuckets(object):
         if cur:
             self._close(cur)
         self._pending = [0] * len(self.buckets)
+        self._diag_left = 400
         self._works = []
         self._next = 0                 # first bucket whose all-reduce has not been issued in this step
         self._views = [(p, p.grad.data_ptr()) for _, plist in self.buckets for p in plist]
@@ -223,6 +285,13 @@ class GradBuckets(object):
         """issue, in bucket order, the all-reduce of every leading bucket that is complete (force: of all that are left)"""
         while self._next < len(self.buckets) and (force or self._pending[self._next] == 0):
             if self.reduce:
+                if _DIAG and self._diag_left > 0:
+                    import sys
+                    import threading
+                    self._diag_left -= 1
+                    sys.stderr.write("[GradBuckets] bucket %d issued from thread %s, stream %s, capturing %s\n" % (
+                        self._next, threading.current_thread().name, torch.cuda.current_stream(),
+                        torch.cuda.is_current_stream_capturing()))
                 op = dist.ReduceOp.AVG if self.in_collective_average else dist.ReduceOp.SUM
                 self._works.append(dist.all_reduce(self.buckets[self._next][0], op=op, group=self.group, async_op=True))
             self._next += 1

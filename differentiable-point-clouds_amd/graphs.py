@@ -12,6 +12,9 @@ What the recipe has to get right (each item was a failure on a real box or is a 
   collective while another one is already recording;
 * ``capture_error_mode="thread_local"``: the RCCL watchdog thread queries events while this thread records, which
   the default (global) mode turns into a capture error;
+* and it must find nothing to query on the communication stream once a collective has forked that stream into the
+  capture: HIP rejects hipEventQuery on an event whose stream is capturing NOW, even if the event was recorded eagerly
+  before (``distributed.drain_watchdog``: seen as a one-in-ten abort on the first run under RCCL, round 5);
 * a capture that fails half way leaves the rank's streams in capture mode and its peers waiting inside a collective:
   with more than one rank the error is raised, not swallowed;
 * nothing may keep the autograd graph of an EARLIER eager call of the same leaves alive while the step is recorded (a
@@ -24,9 +27,19 @@ What the recipe has to get right (each item was a failure on a real box or is a 
   this call; it also loads the newly selected kernels) and recorded again for the calls that follow.  Every rank
   evaluates the key from the same global step, so all ranks re-record in the same call.
 """
+import os
+import sys
+import time
+
 import torch
 
 from . import distributed as dd
+
+
+def _trace(msg):
+    if os.environ.get("DPC_BENCH_TRACE") == "1":
+        sys.stderr.write("[graphs %.3f] %s\n" % (time.perf_counter(), msg))
+        sys.stderr.flush()
 
 
 class RecordedStep(object):
@@ -57,11 +70,17 @@ class RecordedStep(object):
     def _record(self):
         torch.cuda.synchronize(self.device)          # nothing of the previous recording is in flight any more ...
         self.graph, self.out = None, None            # ... before its memory pool is released
+        if os.environ.get("DPC_GC_BEFORE_CAPTURE") == "1":
+            import gc
+            gc.collect()
         if self.collectives:
             dd.barrier(self.device)
+            dd.drain_watchdog()                      # no reaped-late work may be polled while the capture holds RCCL's stream
         graph = torch.cuda.CUDAGraph()
+        _trace("capture begins")
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             out = self._run()
+        _trace("capture ended")
         self.graph, self.out = graph, out
         self.key_value = self._key() if self._key is not None else None
         self.records += 1

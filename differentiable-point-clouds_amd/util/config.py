@@ -86,6 +86,14 @@ class Config(dict):
         self.__dict__["_edits"] = self.__dict__.get("_edits", 0) + 1
         dict.clear(self)
 
+    def popitem(self):
+        self.__dict__["_edits"] = self.__dict__.get("_edits", 0) + 1
+        return dict.popitem(self)
+
+    def __ior__(self, other):            # cfg |= {...}: dict.__ior__ writes without going through update()
+        self.update(other)
+        return self
+
 
 def default_config(**kw):
     return Config(**kw)

@@ -52,9 +52,12 @@ def resize_images_bicubic_tf1(images, size):
     cfg.bicubic_gt_downsampling): the ResizeBicubic op with align_corners=False and the legacy scaler -- source position
     = dst * (in / out) in float, four taps at floor - 1 .. floor + 2 clamped to the image, weights looked up in a
     1024-step table of the A = -0.75 cubic kernel at lrint(frac * 1024), x pass then y pass in float32.
-    Restated from the published op (tensorflow/core/kernels/resize_bicubic_op.cc); PARITY UNPINNED: no TensorFlow
-    binary or golden vector for this branch exists here (the reference switches it off by default,
-    default_config.yaml:96).  images [B,H,W,C] -> [B,size0,size1,C] float32."""
+    Restated after the published op (tensorflow/core/kernels/resize_bicubic_op.cc) and pinned to vectors worked by hand
+    out of that definition (tests/test_tf_shim.py::test_resize_images_bicubic_hand_worked_vectors: integer scales pick
+    pixels, the (-3, 19, 19, -3) / 32 half-way taps with clamped -- not linear-exact -- borders, an 8 -> 3 row in exact
+    rationals); no TensorFlow binary was available, so what stays assumed is the float storage of the table and the
+    x-before-y float32 accumulation order (last-place effects).  The reference switches the branch off by default
+    (default_config.yaml:96).  images [B,H,W,C] -> [B,size0,size1,C] float32."""
     n, ih, iw, c = images.shape
     oh, ow = int(size[0]), int(size[1])
     near, far = _bicubic_table(images.device)

@@ -23,6 +23,8 @@ autograd wired through ``tr_pc``.
 """
 import torch
 
+import weakref
+
 from .. import _capi, ops
 from . import drc as _drc
 
@@ -39,7 +41,7 @@ def _meta(cfg, collapse=None):
     edits = cfg.__dict__.get("_edits") if isinstance(cfg, dict) and hasattr(cfg, "__dict__") else None
     if edits is not None and collapse is None:
         hit = _META_CACHE.get(id(cfg))
-        if hit is not None and hit[0] == edits and hit[1] is cfg:
+        if hit is not None and hit[0] == edits and hit[1]() is cfg:
             return hit[2]
     Dz, D = _dims(cfg)
     c = collapse
@@ -49,7 +51,7 @@ def _meta(cfg, collapse=None):
     if edits is not None and collapse is None:
         if len(_META_CACHE) > 64:
             _META_CACHE.clear()
-        _META_CACHE[id(cfg)] = (edits, cfg, meta)
+        _META_CACHE[id(cfg)] = (edits, weakref.ref(cfg), meta)        # (weak: the cache keeps no config alive)
     return meta
 
 
@@ -99,11 +101,10 @@ _TAPS_CACHE = {}
 def _trim_taps(kernel, taps):
     """central slices (views) of the flattened taps, per axis, for filters tagged with their effective support"""
     support = {}
-    for k in kernel:
+    for k, axis in zip(kernel, _filter_axes(kernel)):
         h = getattr(k, "dpc_support", None)
         if h is not None:
-            kd, kh = int(k.shape[0]), int(k.shape[1])
-            support["z" if kd > 1 else ("y" if kh > 1 else "x")] = int(h)
+            support[axis] = int(h)
     lib = _capi.get_library()
     out = []
     for axis, t in zip("xyz", taps):
@@ -127,19 +128,38 @@ def effective_tap_counts(cfg, kernel, device=None):
     return tuple(0 if t is None else int(t.numel()) for t in _flat_taps(cfg, kernel, dev))
 
 
+def _filter_axes(kernel):
+    """the axis ("x" / "y" / "z") each filter of a separable list runs along.  A filter longer than one tap says so by
+    its shape ([kd,kh,kw,1,1]); a ONE-tap filter -- gauss_kernel.py:35-54 builds one along z whenever
+    round(K * vox_size_z / vox_size) is 1, e.g. vox 112 x 32 deep with K = 5 -- has the shape [1,1,1,1,1] on every axis
+    and takes the first axis no other filter of the list claims, in the order the reference builds and applies them
+    (x, y, z)."""
+    axes = []
+    for k in kernel:
+        shp = tuple(int(v) for v in k.shape)
+        if len(shp) != 5 or shp[3] != 1 or shp[4] != 1:
+            raise ValueError("separable kernel filters must be [kd,kh,kw,1,1], got %s" % (shp,))
+        if sorted(shp[:3])[:2] != [1, 1]:
+            raise ValueError("each separable filter must be 1-D, got %s" % (shp,))
+        axes.append("z" if shp[0] > 1 else ("y" if shp[1] > 1 else ("x" if shp[2] > 1 else None)))
+    free = [a for a in "xyz" if a not in axes]
+    for i, a in enumerate(axes):
+        if a is None:
+            if not free:
+                raise NotImplementedError("two filters along the same axis")
+            axes[i] = free.pop(0)
+    return axes
+
+
 def _flat_taps_uncached(kernel, device):
     taps = {"x": None, "y": None, "z": None}
-    for k in kernel:
-        if not (isinstance(k, torch.Tensor) and k.dtype == torch.float32):
-            k = torch.as_tensor(k, dtype=torch.float32)
-        if k.dim() != 5 or k.shape[3] != 1 or k.shape[4] != 1:
-            raise ValueError("separable kernel filters must be [kd,kh,kw,1,1], got %s" % (tuple(k.shape),))
-        kd, kh, kw = int(k.shape[0]), int(k.shape[1]), int(k.shape[2])
-        if sorted((kd, kh, kw))[:2] != [1, 1]:
-            raise ValueError("each separable filter must be 1-D, got %s" % (tuple(k.shape),))
-        axis = "z" if kd > 1 else ("y" if kh > 1 else "x")
+    kernel = [k if (isinstance(k, torch.Tensor) and k.dtype == torch.float32) else torch.as_tensor(k, dtype=torch.float32)
+              for k in kernel]
+    for k, axis in zip(kernel, _filter_axes(kernel)):
         if taps[axis] is not None:
             raise NotImplementedError("two filters along the same axis")
+        if k.numel() == 1 and float(k.reshape(-1)[0]) == 1.0:
+            continue                      # the normalised one-tap Gaussian: a pass-through along that axis (no launch)
         taps[axis] = k.reshape(-1) if k.device == device else k.reshape(-1).to(device)
     return taps["x"], taps["y"], taps["z"]
 

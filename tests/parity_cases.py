@@ -205,7 +205,8 @@ def rgb_case_matches_goldens(dev, name):
 
 
 # (the *_bicubic cases: cfg.bicubic_gt_downsampling -- the resize is a restatement of TF's ResizeBicubic on both sides
-# of the comparison, see util/losses.resize_images_bicubic_tf1: parity unpinned for that branch)
+# of the comparison (util/losses.resize_images_bicubic_tf1, oracle/tf_shim); what pins BOTH to the op is
+# tests/test_tf_shim.py::test_resize_images_bicubic_hand_worked_vectors, not this comparison)
 LOSS_CASES = ["c1_same", "c1_resize", "c2_x2", "c3_ratio", "c4_valid", "c1_bicubic", "c2_bicubic_x2"]
 
 

@@ -759,6 +759,23 @@ def test_bench_one_rank_rccl_training_step_ddp_and_recorded():
     assert g["value"] > 0
 
 
+def test_recording_beside_the_rccl_watchdog_survives_many_recordings():
+    """25 recordings of a step that holds RCCL collectives, an eager barrier before each (whose work the watchdog still
+    holds when the capture begins): without distributed.drain_watchdog about one recording in ten dies with
+    hipErrorCapturedEvent (HIP refuses hipEventQuery on an event whose STREAM is capturing now; the watchdog polls the
+    barrier's event after the capture has forked RCCL's stream).  scripts/rccl_capture_stress.py --drain 0 shows it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DPC_POISON_BUFFERS",
+                                                            "DPC_WATCHDOG_DRAIN_S")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29643")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "rccl_capture_stress.py"), "--records", "25"], env=env,
+                       cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0 and "OK: 25 recordings" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
+
+
 def test_grad_buckets_equal_ddp_equal_plain_under_one_rank_rccl():
     """One rank, backend nccl: GradBuckets (AVG inside the collective), DistributedDataParallel and the plain
     single-process backward give the same gradients; the recorded GradBuckets step replays to the same values; and RCCL

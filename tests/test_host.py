@@ -216,3 +216,47 @@ def test_emulation_library_is_refused_without_the_test_switch(monkeypatch, emu_l
     monkeypatch.delenv("DPC_TEST_HOOKS", raising=False)
     with pytest.raises(_capi.DpcError, match="DPC_TEST_HOOKS"):
         _capi.set_library(emu_library)
+
+
+def test_config_edit_counter_sees_every_mutator():
+    """util.point_cloud._meta reuses what it derived from a Config until the config's edit counter moves: every way of
+    writing into the mapping must move it (|= and popitem bypass dict.update / __setitem__ in CPython)."""
+    import dpc_amd
+    from dpc_amd.util.point_cloud import _meta
+    cfg = dpc_amd.default_config(vox_size=32)
+    assert _meta(cfg).D == 32
+    cfg |= {"vox_size": 48}
+    assert _meta(cfg).D == 48
+    cfg.vox_size = 64
+    assert _meta(cfg).D == 64
+    n = cfg.__dict__["_edits"]
+    cfg.popitem()
+    assert cfg.__dict__["_edits"] == n + 1
+    import gc, weakref
+    ref = weakref.ref(cfg)
+    del cfg
+    gc.collect()
+    assert ref() is None          # the cache holds no strong reference
+
+
+def test_one_tap_filter_is_the_axis_no_other_filter_claims():
+    """gauss_kernel.py:35-54 builds a ONE-tap z filter when round(K * vox_size_z / vox_size) is 1 (vox 112 x 32 deep,
+    K = 5): its shape [1,1,1,1,1] names no axis; it is the z filter because x and y are taken -- and, being the
+    normalised Gaussian [1.0], a pass-through."""
+    import torch
+    import dpc_amd
+    from dpc_amd.util.point_cloud import _filter_axes, _flat_taps_uncached
+    for D, Dz, K in ((112, 32, 5), (72, 24, 3)):
+        cfg = dpc_amd.default_config(vox_size=D, vox_size_z=Dz, pc_gauss_kernel_size=K)
+        kern = dpc_amd.smoothing_kernel(cfg, 1.0, device="cpu")
+        assert [tuple(k.shape[:3]) for k in kern] == [(1, 1, K), (1, K, 1), (1, 1, 1)]
+        assert _filter_axes(kern) == ["x", "y", "z"]
+        tx, ty, tz = _flat_taps_uncached(kern, torch.device("cpu"))
+        assert tx.numel() == K and ty.numel() == K and tz is None
+    one = torch.ones(1, 1, 1, 1, 1)
+    assert _filter_axes([one, one, one]) == ["x", "y", "z"]
+    z3 = torch.ones(3, 1, 1, 1, 1) / 3
+    assert _filter_axes([one, z3]) == ["x", "z"]
+    import pytest
+    with pytest.raises(NotImplementedError):
+        _filter_axes([z3, z3, one, one, one])

@@ -170,6 +170,64 @@ def test_resize_images_bicubic_legacy_closed_forms():
         assert np.allclose(up[1::2], mid, rtol=0, atol=2e-7)
 
 
+def test_resize_images_bicubic_hand_worked_vectors():
+    """Vectors worked by hand from the PUBLISHED definition of TF r1.x's ResizeBicubic (tensorflow/core/kernels/
+    resize_bicubic_op.cc; what tf.image.resize_images(..., BICUBIC) of model_pc.py:392-397 runs), independent of both
+    restatements under test.  The op, align_corners=False, legacy scaler:
+
+        scale = in / out (float);  for output o:  p = scale * o,  i = (int64) p,  d = p - i,  t = lrintf(d * 1024) / 1024
+        taps at Bound(i - 1), Bound(i), Bound(i + 1), Bound(i + 2)      (Bound clamps to [0, in - 1])
+        weights k(1 + t), k(t), k(1 - t), k(2 - t)   with the cubic convolution kernel, A = -3/4:
+            k(x) = (A + 2) x^3 - (A + 3) x^2 + 1           0 <= x <= 1
+            k(x) = A x^3 - 5 A x^2 + 8 A x - 4 A           1 <  x <  2
+
+    (a) 4 -> 2, scale 2: p = 0, 2 -> t = 0 -> weights (k(1), k(0), k(1), k(2)) = (0, 1, 0, 0): out = (a0, a2), exactly.
+    (b) 4 -> 8 (scale 1/2) of the ramp 0 1 2 3: even outputs land on pixels; odd ones have t = 1/2:
+        k(1/2) = 5/4 / 8 - 9/4 / 4 + 1 = 19/32,  k(3/2) = -3/4 (27/8) + 15/4 (9/4) - 6 (3/2) + 3 = -3/32  -> (-3, 19, 19, -3) / 32.
+        o = 1: taps 0 0 1 2 -> (19 - 6) / 32 = 13/32  (a ramp would give 1/2: the clamped edge is NOT linear-exact, unlike
+        torch's / TF2's half-pixel bicubic -- this is what tells TF1's op apart);  o = 3: taps 0 1 2 3 -> 48/32 = 3/2;
+        o = 5: taps 1 2 3 3 -> (-3 + 38 + 57 - 9) / 32 = 83/32;  o = 7: taps 2 3 3 3 -> (-6 + 57 + 57 - 9) / 32 = 99/32.
+    (c) 8 -> 3 of the squares 0 1 4 ... 49: scale = fl(8/3) = 2.6666667;
+        o = 1: p = 2.6666667, i = 2, d = 0.66666675, lrintf(682.67) = 683, t = 683/1024, taps 1 2 3 4:
+               k(1 + t) = -238259769 / 2^32, k(t) = 1588864607 / 2^32, k(1 - t) = 3421580705 / 2^32, k(2 - t) = -477218247 / 2^32
+               -> (1 * -238259769 + 4 * 1588864607 + 9 * 3421580705 + 16 * -477218247) / 2^32 = 7318983263 / 2^30 = 6.8163343...
+        o = 2: p = 5.3333335, i = 5, t = 341/1024 (the mirrored weights), taps 4 5 6 7:
+               (16 * -477218247 + 25 * 3421580705 + 36 * 1588864607 + 49 * -238259769) / 2^32 = 30857105711 / 2^30 = 28.7379191...
+    (d) a constant stays constant (the four weights sum to one for every t: k is a partition of unity).
+    Both the shim's pixel loop and the product's vectorised version must reproduce them; what remains ASSUMED about the
+    op is only what cannot move these numbers beyond float rounding: the table is stored in float, and the row pass runs
+    before the column pass in float32."""
+    from fractions import Fraction as Fr
+    A = Fr(-3, 4)
+
+    def k(x):                                   # the published kernel, in exact arithmetic: guards the literals above
+        return ((A + 2) * x - (A + 3)) * x * x + 1 if x <= 1 else ((A * x - 5 * A) * x + 8 * A) * x - 4 * A
+    assert (k(Fr(1, 2)), k(Fr(3, 2)), k(Fr(0)), k(Fr(1)), k(Fr(2))) == (Fr(19, 32), Fr(-3, 32), 1, 0, 0)
+    t = Fr(683, 1024)
+    assert [k(1 + t), k(t), k(1 - t), k(2 - t)] == [Fr(-238259769, 2 ** 32), Fr(1588864607, 2 ** 32),
+                                                     Fr(3421580705, 2 ** 32), Fr(-477218247, 2 ** 32)]
+    ramp8 = np.array([0, 13 / 32, 1, 3 / 2, 2, 83 / 32, 3, 99 / 32], np.float32)
+    sq3 = np.array([0.0, 7318983263 / 2 ** 30, 30857105711 / 2 ** 30], np.float32)
+    row = lambda v: np.asarray(v, np.float32).reshape(1, 1, -1, 1)
+    col = lambda v: np.asarray(v, np.float32).reshape(1, -1, 1, 1)
+    for fn in _bicubic_fns():
+        a = np.array([0.3, -1.7, 2.9, 0.45], np.float32)
+        assert np.array_equal(fn(row(a), (1, 2))[0, 0, :, 0], a[[0, 2]])                                   # (a)
+        assert np.array_equal(fn(col(a), (2, 1))[0, :, 0, 0], a[[0, 2]])
+        assert np.abs(fn(row([0, 1, 2, 3]), (1, 8))[0, 0, :, 0] - ramp8).max() <= 3e-7                     # (b) along x
+        assert np.abs(fn(col([0, 1, 2, 3]), (8, 1))[0, :, 0, 0] - ramp8).max() <= 3e-7                     #     along y
+        sq = [i * i for i in range(8)]
+        assert np.abs(fn(row(sq), (1, 3))[0, 0, :, 0] - sq3).max() <= 4e-6                                 # (c)
+        assert np.abs(fn(col(sq), (3, 1))[0, :, 0, 0] - sq3).max() <= 4e-6
+        # separable: a 4 x 4 outer product of the ramp with itself -> 8 x 8 outer product of the worked row
+        im = np.outer(np.arange(4), np.arange(4)).astype(np.float32).reshape(1, 4, 4, 1)
+        assert np.abs(fn(im, (8, 8))[0, :, :, 0] - np.outer(ramp8, ramp8)).max() <= 2e-6
+        assert np.abs(fn(np.full((1, 5, 7, 2), -2.25, np.float32), (3, 4)) + 2.25).max() <= 5e-7            # (d)
+    # and the same ramp through torch's own bicubic (half-pixel centres): NOT these numbers -- the product must not call it
+    up = torch.nn.functional.interpolate(torch.arange(4.0).view(1, 1, 1, 4), size=(1, 8), mode="bicubic", align_corners=False)
+    assert np.abs(up.numpy().ravel() - ramp8).max() > 0.1
+
+
 @pytest.mark.parametrize("shape,size", [((2, 128, 128, 1), (64, 64)), ((1, 7, 10, 2), (5, 3)), ((1, 5, 5, 1), (5, 5)),
                                         ((1, 96, 96, 1), (64, 64)), ((1, 4, 4, 1), (9, 7))])
 def test_resize_images_bicubic_product_equals_the_loop_restatement(shape, size):
