@@ -50,6 +50,7 @@
 
 #include "k_prelude.inc"
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -112,6 +113,8 @@ int dpc_compiled_taps(int K) {
     if (tap_compiled(k)) return k;
   return 0;
 }
+
+int dpc_set_chunk_sparse(int mode) { return chunk_sparse_mode().exchange(mode < 0 ? -1 : (mode ? 1 : 0)); }
 
 int dpc_profile_enable(int on) {
   dpcprof::clear();

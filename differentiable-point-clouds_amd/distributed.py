@@ -52,7 +52,7 @@ def init(backend=None, device=None, force=None):
         kw = {"device_id": device} if device.type == "cuda" else {}
         with _stdout_to_stderr():     # RCCL prints a version banner on STDOUT when its first communicator comes up;
             dist.init_process_group(backend, rank=rank, world_size=world, **kw)      # stdout is for the ONE JSON line
-            if backend == "nccl":
+            if backend == "nccl" and os.environ.get("DPC_INIT_BARRIER", "1") == "1":
                 dist.barrier()        # the communicator is created here at the latest
                 torch.cuda.synchronize(device)
     return rank, world, device
@@ -151,20 +151,25 @@ def barrier(device=None):
 
 
 def drain_watchdog(seconds=None):
-    """Give ProcessGroupNCCL's watchdog thread time to reap the works of the collectives issued so far; call it after a
-    synchronize and BEFORE starting a HIP-graph capture that will hold collectives.
+    """Give ProcessGroupNCCL's watchdog thread time to reap the works of the collectives issued so far; called after a
+    synchronize and BEFORE a HIP-graph capture that will hold collectives.  A precaution, not a proven fix:
 
-    Why (found on the first contact of this code with RCCL, round 5, profiles/r05/rccl_world1.txt): the watchdog polls
-    its list of outstanding works every 100 ms with hipEventQuery on each work's end event.  Those events were recorded
-    -- eagerly -- on the process group's communication stream.  A capture that contains a collective forks that very
-    stream into the capture, and HIP answers hipEventQuery with hipErrorCapturedEvent whenever the stream an event was
-    LAST RECORDED ON is capturing at the moment of the query (CUDA looks at the event itself), so a work that is
-    complete but not yet reaped -- the barrier right before the capture always is -- kills the process through the
-    watchdog's exception ("operation not permitted on an event last recorded in a capturing stream"), in about one run
-    in ten.  torch 2.10 no longer holds captures back until the watchdog's list is empty (the pending-event-query
-    counter of earlier releases is gone) and exposes no call that waits for it, so: everything issued so far has
-    completed (the caller synchronised), the next poll removes it, and two and a half poll periods are waited for here.
-    Works created DURING the capture are never handed to the watchdog (ProcessGroupNCCL checks the capture status)."""
+    The very first run of this code under RCCL (round 5, one rank, `bench.py --config 3 --graph --force-dist`; log in
+    profiles/r05/rccl_first_contact_abort.txt) was killed by the watchdog: its poll of a work's end event
+    (WorkNCCL::isCompleted -> hipEventQuery) came back with hipErrorCapturedEvent ("operation not permitted on an event
+    last recorded in a capturing stream"), which ProcessGroupNCCL turns into std::terminate.  It has not been seen
+    again: 0 of 50 further runs of the same command (cold and warm MIOpen caches, with and without this pause, with
+    and without a collective between init and the first bucket all-reduce), 0 of 360 re-recordings of the training
+    step with an eager barrier right before each capture and this pause switched off (scripts/rccl_capture_stress.py),
+    and a probe that holds a capture open for 0.5 s around a collective -- with a completed-but-unreaped eager work in
+    the watchdog's list, and with the capture-time work itself -- passes in every variant
+    (scripts/rccl_capture_probe.py).  So neither "the watchdog polls an eager event whose stream has since been forked
+    into the capture" nor "works created during the capture are polled" reproduces it on demand; the one thing known
+    is that the query and a capture overlapped.  torch 2.10 no longer holds a capture back until the watchdog's list
+    is empty (the pending-event-query counter of earlier releases is gone) and exposes no call that waits for it;
+    pausing 2.5 poll periods (the watchdog sleeps 100 ms between polls) once everything issued has completed leaves
+    that list empty when the capture begins, which removes one of the two candidates at the price of 0.25 s per
+    recording.  DPC_WATCHDOG_DRAIN_S=0 switches it off."""
     if not active() or dist.get_backend() != "nccl":
         return
     if seconds is None:

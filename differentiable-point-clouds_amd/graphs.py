@@ -12,9 +12,9 @@ What the recipe has to get right (each item was a failure on a real box or is a 
   collective while another one is already recording;
 * ``capture_error_mode="thread_local"``: the RCCL watchdog thread queries events while this thread records, which
   the default (global) mode turns into a capture error;
-* and it must find nothing to query on the communication stream once a collective has forked that stream into the
-  capture: HIP rejects hipEventQuery on an event whose stream is capturing NOW, even if the event was recorded eagerly
-  before (``distributed.drain_watchdog``: seen as a one-in-ten abort on the first run under RCCL, round 5);
+* the watchdog's list of outstanding works is given time to empty before the capture begins
+  (``distributed.drain_watchdog``): the first run under RCCL (round 5) was killed by a watchdog poll that came back
+  with hipErrorCapturedEvent; not reproduced in 50 runs and 360 re-recordings since -- a precaution, see there;
 * a capture that fails half way leaves the rank's streams in capture mode and its peers waiting inside a collective:
   with more than one rank the error is raised, not swallowed;
 * nothing may keep the autograd graph of an EARLIER eager call of the same leaves alive while the step is recorded (a
@@ -75,7 +75,7 @@ class RecordedStep(object):
             gc.collect()
         if self.collectives:
             dd.barrier(self.device)
-            dd.drain_watchdog()                      # no reaped-late work may be polled while the capture holds RCCL's stream
+            dd.drain_watchdog()                      # (precaution: the watchdog's list is empty when the capture begins)
         graph = torch.cuda.CUDAGraph()
         _trace("capture begins")
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):

@@ -147,10 +147,12 @@ int dpc_debug_fill(dpc_stream_t stream, float* dst, size_t n, float value, int v
  * 4*B*N bytes ([B,2,N,2]: view, corner plane, sorted slot, corner row), one bit per touched trilinear corner (fused path: points are
  * bucketed by depth cell and splatted into per-plane LDS tiles, the raw grid
  * never reaches HBM); bit 2 (value 4) = point_index, int32
- * [dpc_point_index_ints(shape)] = 5*B*N + B*(Dz+2) + B*8 (16-byte aligned): the points of
+ * [dpc_point_index_ints(shape)] = 5*B*N + B*(Dz+2) + B*8 (+ the chunk maps below; 16-byte aligned): the points of
  * each view sorted by depth cell as 16-byte records (w, v, u, original index), the inverse
  * map (slot of point n), the bucket starts, and 8 words of plane-occupancy bits per view, which the backward
- * re-uses (set together with bit 1; clip_mask is indexed by the sorted slot);
+ * re-uses (set together with bit 1; clip_mask is indexed by the sorted slot); for grids whose rows are whole
+ * 32-ray words (D % 32 == 0) also the chunk maps of the chunk-sparse grid layout: B*D*(D/32)*8 words (bit z of
+ * entry (b, y, c): the 128-byte chunk c of row y of plane z holds anything) and B*Dz*D bytes (the same by plane);
  * bit 3 (value 8, informational) = grid_blur holds the xy-blurred grid rather
  * than G2.  Buffers that are not used may be null.  <0 on error. */
 int dpc_saved_layout(const DpcShape* shape, const DpcParams* params);
@@ -165,6 +167,13 @@ int dpc_silhouette_select(dpc_stream_t stream, int B, int C, int nparts, const f
 /* Number of int32 elements of the point_index buffer (0 when the shape does not
  * use it). */
 size_t dpc_point_index_ints(const DpcShape* shape);
+/* Chunk-sparse grids (new; no reference counterpart -- the reference's grids are dense TF tensors,
+ * dpc/util/point_cloud.py:60-145): the fused path stores, and later reads, only the 128-byte chunks of the saved /
+ * gradient grids that lie within the blur's reach of a point on their plane; whether a shape uses it is the
+ * library's choice (short filters against the grid width).  mode 0 / 1 forces it off / on for the calls that follow
+ * (forward and backward of one step must see the same mode), -1 restores the rule; returns the previous mode.
+ * For A/B measurements and for tests that compare the two forms bit for bit. */
+int dpc_set_chunk_sparse(int mode);
 
 /* Bytes of scratch `dpc_project_forward` (direction 0) / `dpc_project_backward`
  * (direction 1) need.  256-byte aligned device memory. */

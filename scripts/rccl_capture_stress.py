@@ -23,6 +23,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--records", type=int, default=40)
     ap.add_argument("--drain", type=float, default=None, help="seconds (default: the library's 0.25); 0 = off")
+    ap.add_argument("--step", default="mlp", choices=["mlp", "train"],
+                    help="mlp: twelve linear layers (a capture of ~1 ms); train: the chair_unsupervised training step "
+                         "(~250 launches, a capture of ~7 ms: the window the first RCCL run of round 5 died in)")
+    ap.add_argument("--batch", type=int, default=4)
     args = ap.parse_args()
     if args.drain is not None:
         os.environ["DPC_WATCHDOG_DRAIN_S"] = str(args.drain)
@@ -31,20 +35,35 @@ def main():
     dd = dpc_amd.distributed
     rank, world, dev = dd.init("nccl", force=True)
     torch.manual_seed(0)
-    net = torch.nn.Sequential(*[torch.nn.Linear(1024, 1024) for _ in range(12)]).to(dev)
-    red = dd.GradBuckets(net.parameters(), bucket_mb=8)
-    x = torch.randn(256, 1024, device=dev)
+    if args.step == "mlp":
+        net = torch.nn.Sequential(*[torch.nn.Linear(1024, 1024) for _ in range(12)]).to(dev)
+        red = dd.GradBuckets(net.parameters(), bucket_mb=8)
+        x = torch.randn(256, 1024, device=dev)
 
-    def run():
-        red.zero_()
-        net(x).square().mean().backward()
-        red.finish()
+        def run():
+            red.zero_()
+            net(x).square().mean().backward()
+            red.finish()
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "examples", "chair_unsupervised"))
+        import train_step as ts
+        from nets import Im2PointCloud
+        cfg = ts.make_cfg(batch_size=args.batch, pc_point_dropout=1.0, pc_point_dropout_scheduled=False)
+        net = Im2PointCloud(cfg, 128).to(dev)
+        red = dd.GradBuckets(net.parameters(), bucket_mb=64)
+        projector = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device=dev)
+        torch.backends.cudnn.benchmark = True
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=True, fused=True)
+        inputs = ts.synthetic_batch(cfg, dev, 128, seed=0)
+        projector.enable_graph_replay(follow_tap_counts=True)
+        run = lambda: ts.train_step(net, projector, inputs, opt, world, buckets=red)
     t0 = time.perf_counter()
     step = dpc_amd.graphs.RecordedStep(run, world=world, device=dev, collectives=True)
     for i in range(args.records - 1):
         for _ in range(5):
             step()
         dd.barrier(dev)                  # an eager collective: its work sits in the watchdog's list for up to 100 ms
+        sys.stderr.write("[stress] recording %d\n" % (i + 2))
         step._record()
     for _ in range(5):
         step()

@@ -18,7 +18,7 @@ def is_rccl(name):
 
 for f in sorted(glob.glob(os.path.join(out, "21_bench_*.json"))):
     try:
-        j = json.load(open(f))
+        j = json.loads([l for l in open(f) if l.startswith("{")][0])      # (RCCL's banner may precede the line)
         print("%-32s %9.0f views/s  %.3f ms/step  hip_graph=%s\n    parallelism: %s" % (
             os.path.basename(f)[9:-5], j["value"], j["ms_per_step"], j["config"]["hip_graph"], j["config"]["parallelism"]))
     except Exception as e:   # noqa: BLE001
@@ -54,8 +54,10 @@ for tag in ("rccl_graph", "rccl_ddp"):
                 print("     %s [q%s] %9.1f us  %s" % ("->" if jx == i else "  ", r.get("Queue_Id", "?"),
                                                      (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, names[jx][:100]))
             print("     --")
-    lib = sum(1 for n in names if n.startswith("dpck::") or "dpck::" in n)
-    print("   library (dpck::) launches in the trace: %d" % lib)
+    ours = ("k_zsort", "k_zhist", "k_zscatter", "k_splat_xy", "k_zfwd", "k_zbwd", "k_gather_yx", "k_points_bwd", "k_sum_views",
+            "k_sil_", "k_student", "k_cs_")
+    lib = sum(1 for n in names if any(k in n for k in ours))
+    print("   this library's kernels in the same trace: %d launches" % lib)
 
 print()
 for f in sorted(glob.glob(os.path.join(out, "24_stress_*.log"))):

@@ -760,10 +760,9 @@ def test_bench_one_rank_rccl_training_step_ddp_and_recorded():
 
 
 def test_recording_beside_the_rccl_watchdog_survives_many_recordings():
-    """25 recordings of a step that holds RCCL collectives, an eager barrier before each (whose work the watchdog still
-    holds when the capture begins): without distributed.drain_watchdog about one recording in ten dies with
-    hipErrorCapturedEvent (HIP refuses hipEventQuery on an event whose STREAM is capturing now; the watchdog polls the
-    barrier's event after the capture has forked RCCL's stream).  scripts/rccl_capture_stress.py --drain 0 shows it."""
+    """25 recordings of a step that holds RCCL collectives beside the live watchdog thread, an eager barrier before each
+    (the first run under RCCL was killed by a watchdog poll that overlapped a capture -- distributed.drain_watchdog; this
+    is the regression test that recording and re-recording keep working, not a reproduction of that abort)."""
     import os
     import subprocess
     import sys
