@@ -151,8 +151,8 @@ int dpc_debug_fill(dpc_stream_t stream, float* dst, size_t n, float value, int v
  * each view sorted by depth cell as 16-byte records (w, v, u, original index), the inverse
  * map (slot of point n), the bucket starts, and 8 words of plane-occupancy bits per view, which the backward
  * re-uses (set together with bit 1; clip_mask is indexed by the sorted slot); for grids whose rows are whole
- * 32-ray words (D % 32 == 0) also the chunk maps of the chunk-sparse grid layout: B*D*(D/32)*8 words (bit z of
- * entry (b, y, c): the 128-byte chunk c of row y of plane z holds anything) and B*Dz*D bytes (the same by plane);
+ * 32-ray words (D % 32 == 0) also the chunk maps of the chunk-sparse grid layout: two copies of B*Dz*D bytes (bit c
+ * of the byte of (view, plane, row): the 128-byte chunk c of that row holds anything), ordered by plane and by row;
  * bit 3 (value 8, informational) = grid_blur holds the xy-blurred grid rather
  * than G2.  Buffers that are not used may be null.  <0 on error. */
 int dpc_saved_layout(const DpcShape* shape, const DpcParams* params);

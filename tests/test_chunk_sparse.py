@@ -1,6 +1,7 @@
 """Chunk-sparse grids (csrc/k_prelude.inc, host_launch.inc chunk_sparse_on): the fused path stores / loads only the 128-byte
 chunks of the saved and gradient grids that lie within the blur's reach of a point on their plane.  It is a layout decision,
-not an approximation: with dpc_set_chunk_sparse(0 / 1) the two forms must agree BIT FOR BIT in every output and gradient,
+not an approximation: with dpc_set_chunk_sparse(0 / 1) the two forms must agree BIT FOR BIT in the images and in the point
+gradients (the per-view pose / scale sums, which run through float atomics, to their run-to-run noise),
 the sparse form must leave most of the saved grid unwritten, and the reference-convention cases must hold in both."""
 import ctypes
 
@@ -59,10 +60,10 @@ def sparse_form_writes_fewer_chunks_and_the_same_images(lib, D, K, N, dev="cpu")
     assert np.isnan(gs).mean() > np.isnan(gd).mean() + 0.2               # a good part of the grid is never stored
 
 
-def both_forms_agree_bit_for_bit(lib, dev, B, N, D, K, sigma, seed=7):
+def both_forms_agree_bit_for_bit(lib, dev, B, N, D, K, sigma, seed=7, Dz=-1):
     """product API, forward + every gradient, chunk-sparse forced off and on"""
     inp = dpc_amd.synthetic.make_inputs(B, N, seed)
-    cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K)
+    cfg = dpc_amd.default_config(vox_size=D, vox_size_z=Dz, pc_gauss_kernel_size=K)
     kern = dpc_amd.smoothing_kernel(cfg, sigma, device=dev)
     gt = torch.tensor(dpc_amd.synthetic.disk_gt(B, D), device=dev)
     res = []
@@ -75,9 +76,10 @@ def both_forms_agree_bit_for_bit(lib, dev, B, N, D, K, sigma, seed=7):
         res.append([out["proj"].detach().cpu().numpy(), out["proj_depth"].detach().cpu().numpy()] + [x.cpu().numpy() for x in g])
     lib.dpc_set_chunk_sparse(-1)
     for a, b, name in zip(res[0], res[1], ("proj", "depth", "dpc", "dpose", "dscale")):
-        if dev != "cpu" and name in ("dpose", "dscale"):
-            # (on the device the per-view pose sums go through float atomics: run-to-run differences in the last places)
-            assert np.abs(a - b).max() <= 2e-6 * max(np.abs(a).max(), 1e-30), (name, float(np.abs(a - b).max()))
+        if name in ("dpose", "dscale"):
+            # (the per-view pose sums of several work-groups go through float atomics: two runs of the SAME form already
+            # differ in the last places, on the device and -- its threads are OS threads -- in the emulation)
+            assert np.abs(a - b).max() <= 3e-6 * max(np.abs(a).max(), 1e-30), (name, float(np.abs(a - b).max()))
         else:
             assert np.array_equal(a, b), (name, float(np.abs(a - b).max()))
 
@@ -90,6 +92,12 @@ def test_emu_sparse_form_writes_fewer_chunks_and_the_same_images(lib, D, K, N):
 @pytest.mark.parametrize("case", [(2, 300, 32, 5, 0.9), (2, 500, 64, 9, 1.4), (1, 400, 64, 21, 3.0)])
 def test_emu_both_forms_agree_bit_for_bit(lib, case):
     both_forms_agree_bit_for_bit(lib, "cpu", *case)
+
+
+def test_emu_both_forms_agree_on_a_256_wide_grid(lib):
+    """256-wide rows: a wavefront of the z kernels covers HALF a row (chunks 0-3 or 4-7 of its eight); shallow (32 planes: one
+    partly filled 64-plane block of the byte map) to keep the emulation quick"""
+    both_forms_agree_bit_for_bit(lib, "cpu", 1, 600, 256, 5, 1.0, Dz=32)
 
 
 @pytest.mark.parametrize("mode", [0, 1])

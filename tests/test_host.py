@@ -68,8 +68,8 @@ def test_c_abi_argument_validation_without_gpu():
     S64 = _capi.DpcShape(2, 10, 64, 64, 11, 11, 11)
     assert lib.dpc_saved_layout(ctypes.byref(S64), ctypes.byref(P)) == 6 | 8   # fused path: clip_mask + point_index; xy grid saved
     # records + inverse map + bucket starts + plane-occupancy words, and (rows of whole 32-ray words) the chunk maps:
-    # B D (D/32) 8 ray-major words + B Dz D plane-major bytes
-    assert lib.dpc_point_index_ints(ctypes.byref(S64)) == 5 * 2 * 10 + 2 * 66 + 2 * 8 + 2 * 64 * 2 * 8 + 2 * 64 * 64 // 4
+    # a byte per (view, plane, row), once by plane and once by row
+    assert lib.dpc_point_index_ints(ctypes.byref(S64)) == 5 * 2 * 10 + 2 * 66 + 2 * 8 + 2 * (2 * 64 * 64 // 4)
     S48 = _capi.DpcShape(2, 10, 48, 48, 5, 5, 5)                               # 48 on the 64-wide geometry: no chunk maps
     assert lib.dpc_point_index_ints(ctypes.byref(S48)) == 5 * 2 * 10 + 2 * 50 + 2 * 8
     S21 = _capi.DpcShape(2, 10, 64, 64, 21, 21, 21)
