@@ -137,23 +137,44 @@ def build_train_case(args, device, rank, world):
     return case
 
 
-def plane_occupancy(case):
+def plane_occupancy(case, k_run=None, chunk_sparse=False):
     """Occupied planes per view (k_splat_xy writes, k_zfwd / k_zbwd / k_gather_yx read only planes that hold trilinear
     mass: a valid point in depth cell z-1 or z), counted on the host from one forward call's tr_pc -- so that the byte
-    counts below are what the kernels have to move for THESE clouds, not a dense-grid model."""
+    counts below are what the kernels have to move for THESE clouds, not a dense-grid model.  With the chunk-sparse
+    layout (third entry of the result, else None) also the 128-byte chunks the kernels touch: chunk c of row y of plane
+    z holds anything iff a point has a corner on plane z whose corner rows lie within K/2 rows of y and whose corner
+    columns, widened by K/2, reach into columns 32 c .. 32 c + 31 (the marks k_splat_xy leaves: geometry, not values)."""
     with torch.no_grad():
         out = dpc_amd.pointcloud_project_fast(case["cfg"], case["pc"], case["pose"], None, None, case["kern"],
                                               scaling_factor=case["scale"])
         tr = out["tr_pc"].detach().cpu().numpy().astype(np.float32)
     D = case["D"]
     valid = np.all((tr >= -0.5) & (tr <= 0.5), axis=-1)
-    iz = np.floor((tr[..., 0] + np.float32(0.5)) * np.float32(D - 1)).astype(np.int64).clip(0, D - 1)
+    cell = lambda i: np.floor((tr[..., i] + np.float32(0.5)) * np.float32(D - 1)).astype(np.int64).clip(0, D - 1)
+    iz = cell(0)
     live = 0
     for b in range(tr.shape[0]):
         cells = np.zeros(D + 1, dtype=bool)
         cells[iz[b][valid[b]]] = True
         live += int((cells[:D] | np.concatenate([[False], cells[:D - 1]])).sum())
-    return live, int(valid.sum())
+    chunks = None
+    if chunk_sparse:
+        H = int(k_run if k_run is not None else case["K"]) // 2
+        iy, ix = cell(1), cell(2)
+        chunks = 0
+        for b in range(tr.shape[0]):
+            v = valid[b]
+            z0, y0, x0 = iz[b][v], iy[b][v], ix[b][v]
+            mark = np.zeros((D + 1, D, D // 32), dtype=bool)
+            c_lo, c_hi = np.maximum(x0 - H, 0) >> 5, np.minimum(x0 + 1 + H, D - 1) >> 5
+            for dy in range(-H, H + 2):
+                y = y0 + dy
+                ok = (y >= 0) & (y < D)
+                for dz in (0, 1):
+                    for c in (c_lo, c_hi):               # (2 H + 2 <= 32 columns: at most two chunks)
+                        mark[z0[ok] + dz, y[ok], c[ok]] = True
+            chunks += int(mark[:D].sum())
+    return live, int(valid.sum()), chunks
 
 
 def kernel_bytes(label, case, save_xy, occ):
@@ -163,16 +184,23 @@ def kernel_bytes(label, case, save_xy, occ):
     plane = 4 * D * D
     L = occ[0] if occ else B * D                     # planes that exist
     img = B * plane                                  # one [B,D,D] image
+    if occ and len(occ) > 2 and occ[2] is not None:
+        # chunk-sparse layout: of the occupied planes only the marked 128-byte chunks move (L in units of planes), plus the
+        # chunk marks themselves (a byte per row of an occupied plane, written twice by the splat, read once per consumer)
+        marks = L * D
+        L = occ[2] * 128.0 / plane
+    else:
+        marks = 0
     fused = {
         # points 12 B in; tr_pc 12 + record 16 + slot 4 out
         "zsort": (B * N * 12, B * N * 32), "zhist": (B * N * 12, B * N * 16), "zscatter": (B * N * 16, B * N * 20),
         # every point's record is read by the two planes it touches; 4 clip bytes per point; occupied planes out
-        "splat_xy": (B * N * 32, L * plane + B * N * 4),
+        "splat_xy": (B * N * 32, L * plane + B * N * 4 + 2 * marks),
         # occupied planes in (+ all of G2 out at > 11 taps); proj, depth, loss gradient (+ its target in), fp64 sums
-        "zfwd": (L * plane + img, (0 if save_xy else B * D * plane) + 3 * img + 4 * img),
-        "zbwd": ((L if save_xy else B * D) * plane + 4 * img + img, L * plane),
+        "zfwd": (L * plane + img + marks, (0 if save_xy else B * D * plane) + 3 * img + 4 * img),
+        "zbwd": ((L if save_xy else B * D) * plane + 4 * img + img + marks, L * plane),
         # occupied planes + records + clip bytes in; 12-byte partials out (2 or 4 per point)
-        "gather_yx": (L * plane + B * N * 32 + B * N * 4, B * N * 12 * (2 if D <= 64 else 4)),
+        "gather_yx": (L * plane + B * N * 32 + B * N * 4 + marks, B * N * 12 * (2 if D <= 64 else 4)),
         "points_bwd": (B * N * (12 * (2 if D <= 64 else 4) + 12 + 12 + 4), B * N * 12),
     }
     if label in fused:
@@ -591,7 +619,8 @@ def main():
         # the clouds themselves; training step: the dense model, the clouds are the decoder's output)
         fused_path = dpc_amd.ops.uses_fused_path(lib, case["B"], case["N"], dpc_amd.util.point_cloud._meta(
             dpc_amd.default_config(vox_size=case["D"])), (k_run,) * 3)
-        occ = None if (train or not fused_path) else plane_occupancy(case)
+        cs_on = bool(fused_path) and lib.chunk_sparse(case["B"], case["N"], case["D"], k_run)
+        occ = None if (train or not fused_path) else plane_occupancy(case, k_run, cs_on)
         by_kernel = {k: kernel_bytes(k, case, save_xy, occ) for k in per_step}
         rd, wr = by_kernel[dom]
         launches_per_step = agg[dom][0] / psteps
@@ -614,8 +643,12 @@ def main():
                 "measured_achieved": None if traffic is None else traffic / (dom_ms * 1e-3) / 1e9,
                 "kernel_ms": dom_ms, "kernel_launches_per_step": launches_per_step,
                 "kernel_bytes": {"read": rd, "written": wr,
-                                 "basis": ("occupied planes of this run's clouds (%d of %d) + point records + images"
-                                           % (occ[0], case["B"] * case["D"]) if occ else "dense planes + point records + images")},
+                                 "basis": (("occupied planes of this run's clouds (%d of %d)%s + point records + images"
+                                            % (occ[0], case["B"] * case["D"],
+                                               (", of which the marked 128-byte chunks (%d of %d: chunk-sparse layout) and their marks"
+                                                % (occ[2], case["B"] * case["D"] ** 3 // 32)) if occ[2] is not None else ""))
+                                           if occ else "dense planes + point records + images")},
+                "chunk_sparse": bool(occ and occ[2] is not None),
                 "ceilings": ceil, "kernel_ceiling": kceil, "vs_ceiling": None if not kceil else ach / kceil,
                 "taps_run": k_run, "saves_xy_grid": bool(save_xy),
                 "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items())},

@@ -144,6 +144,14 @@ class DpcLibrary(object):
         params = DpcParams(2.0, 1.875, 1e-5, 10.0, 1, DPC_COLLAPSE_DRC, 0, 0, 0)
         return bool(self.dpc_saved_layout(ctypes.byref(shape), ctypes.byref(params)) & 8)
 
+    def chunk_sparse(self, B, N, D, K, Dz=None):
+        """True when the fused path stores / loads only the chunks within the blur's reach of a point at this shape
+        (bit 4 of dpc_saved_layout; dpc_set_chunk_sparse forces it): bench.py's byte model counts those chunks then."""
+        shape = DpcShape(int(B), int(N), int(Dz or D), int(D), int(K), int(K), int(K))
+        params = DpcParams(2.0, 1.875, 1e-5, 10.0, 1, DPC_COLLAPSE_DRC, 0, 0, 0)
+        layout = self.dpc_saved_layout(ctypes.byref(shape), ctypes.byref(params))
+        return layout >= 0 and bool(layout & 2) and bool(layout & 16)
+
     @staticmethod
     def check(rc, what):
         if rc == 0:

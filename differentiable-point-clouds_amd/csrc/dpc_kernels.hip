@@ -126,8 +126,9 @@ int dpc_profile_enable(int on) {
 int dpc_saved_layout(const DpcShape* shape, const DpcParams* params) {
   if (check_shape(shape, true) != DPC_OK || !params) return DPC_E_SHAPE;
   if (!splat_plan(*shape).ok) return 1;   // bit 0: grid_raw
-  // bits 1+2: clip_mask + point_index; bit 3 (informational): grid_blur holds the xy-blurred grid, not G2
-  return 6 | (save_xy_mode(*shape, params->collapse_mode == DPC_COLLAPSE_DRC) ? 8 : 0);
+  // bits 1+2: clip_mask + point_index; bit 3 (informational): grid_blur holds the xy-blurred grid, not G2;
+  // bit 4 (informational): the grids are chunk-sparse for this shape right now (the rule, or dpc_set_chunk_sparse)
+  return 6 | (save_xy_mode(*shape, params->collapse_mode == DPC_COLLAPSE_DRC) ? 8 : 0) | (chunk_sparse_on(*shape) ? 16 : 0);
 }
 
 size_t dpc_sil_parts_per_view(const DpcShape* shape) {

@@ -154,7 +154,9 @@ int dpc_debug_fill(dpc_stream_t stream, float* dst, size_t n, float value, int v
  * 32-ray words (D % 32 == 0) also the chunk maps of the chunk-sparse grid layout: two copies of B*Dz*D bytes (bit c
  * of the byte of (view, plane, row): the 128-byte chunk c of that row holds anything), ordered by plane and by row;
  * bit 3 (value 8, informational) = grid_blur holds the xy-blurred grid rather
- * than G2.  Buffers that are not used may be null.  <0 on error. */
+ * than G2; bit 4 (value 16, informational) = the saved and gradient grids are chunk-sparse for this shape at the
+ * moment (dpc_set_chunk_sparse): only chunks within the blur's reach of a point are written / read, the rest of
+ * grid_blur is left untouched.  Buffers that are not used may be null.  <0 on error. */
 int dpc_saved_layout(const DpcShape* shape, const DpcParams* params);
 /* Partial sums per instance that the fused silhouette-loss epilogue leaves in DpcParams.sil_err_parts
  * (= the collapse kernel's work-groups per view), 0 when the shape cannot use it. */

@@ -20,13 +20,14 @@ def lib(emu):
     lib.dpc_set_chunk_sparse(-1)
 
 
-def _forward_raw(lib, D, K, N, B=2, radius=0.2, dev="cpu"):
+def _forward_raw(lib, D, K, N, B=2, radius=0.2, dev="cpu", pc=None, pose=None, sigma=0.9):
     """dpc_project_forward on caller buffers whose saved grid starts as NaN: what stays NaN was never written"""
     rng = np.random.default_rng(1)
-    pc = torch.tensor((rng.normal(size=(B, N, 3)) * radius / 2).clip(-radius, radius).astype(np.float32), device=dev)
-    pose = torch.tensor(rng.normal(size=(B, 4)).astype(np.float32), device=dev)
+    if pc is None:
+        pc = torch.tensor((rng.normal(size=(B, N, 3)) * radius / 2).clip(-radius, radius).astype(np.float32), device=dev)
+        pose = torch.tensor(rng.normal(size=(B, 4)).astype(np.float32), device=dev)
     cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K)
-    taps = [k.reshape(-1).contiguous() for k in dpc_amd.smoothing_kernel(cfg, 0.9, device=dev)]
+    taps = [k.reshape(-1).contiguous() for k in dpc_amd.smoothing_kernel(cfg, sigma, device=dev)]
     S = dpc_amd._capi.DpcShape(B, N, D, D, K, K, K)
     P = dpc_amd._capi.DpcParams(2.0, 1.875, 1e-5, 10.0, 1, 0, 0, 0, 0)
     z = lambda *s, **kw: torch.zeros(*s, device=dev, **kw)
@@ -109,6 +110,25 @@ def test_emu_reference_conventions_hold_in_both_forms(lib, mode):
     parity_cases.fused_dropout_equals_explicit_subset("cpu", extras=False)
     parity_cases.fused_candidate_loss_equals_the_image_epilogue("cpu", N=100)
     parity_cases.fused_path_against_numpy_oracle("cpu", *parity_cases.DENSE_GATHER_CASE_EMU)
+
+
+def test_bench_counts_the_chunks_the_kernels_mark(lib):
+    """bench.py's byte model for the chunk-sparse layout counts marked chunks on the host (plane_occupancy): it must be the
+    number of chunks k_splat_xy really stores (here: the 128-byte chunks of a NaN-initialised saved grid that came back written)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    for cid, D, K, N, sigma in ((97, 64, 5, 400, 0.9), (98, 32, 7, 300, 1.2), (99, 128, 11, 500, 1.6)):
+        dpc_amd.synthetic.CONFIGS[cid] = dict(B=2, N=N, D=D, K=K, sigma=sigma)
+        case = bench.build_case(cid, None, torch.device("cpu"))
+        lib.dpc_set_chunk_sparse(1)
+        live, nvalid, chunks = bench.plane_occupancy(case, K, True)
+        grid, _, _ = _forward_raw(lib, D, K, N, pc=case["pc"].detach(), pose=case["pose"].detach(), sigma=sigma)
+        written = ~np.isnan(grid.reshape(2, D, D, D // 32, 32))
+        assert np.all(written.all(-1) == written.any(-1))              # chunks are stored whole
+        assert int(written.any(-1).sum()) == chunks, (D, K, int(written.any(-1).sum()), chunks)
+        assert chunks < 2 * D * D * D // 32 and live <= 2 * D and nvalid <= 2 * N
 
 
 def test_the_rule_and_the_switch(lib):
