@@ -46,6 +46,20 @@ B() {  # name, bench args...
   NAME=$1; shift
   timeout 400 python bench.py --gpus 1 "$@" > "$OUT/03_bench_$NAME.json" 2> "$OUT/03_bench_$NAME.err"; echo "bench $NAME rc=$?"
 }
+if has ab; then
+  # chunk-sparse layout forced off against the per-shape rule (the default)
+  timeout 600 python -m pytest tests/test_chunk_sparse.py -m gpu -q -p no:cacheprovider > "$OUT/30_pytest_chunk_sparse.log" 2>&1
+  echo "pytest chunk-sparse exit $?" | tee -a "$OUT/30_pytest_chunk_sparse.log"; tail -3 "$OUT/30_pytest_chunk_sparse.log"
+  for MODE in 0 rule; do
+    if [ $MODE = 0 ]; then export DPC_CHUNK_SPARSE_ON=0; else unset DPC_CHUNK_SPARSE_ON; fi
+    B cfg2_cs$MODE --steps 50 --warmup 10 --no-cpu-baseline
+    B cfg5_cs$MODE --steps 30 --warmup 5 --config 5 --no-cpu-baseline
+    for S in 3.0 0.8 0.3; do
+      B cfg3p_sigma${S}_cs$MODE --steps 30 --warmup 5 --config 3 --projector-only --sigma $S --no-cpu-baseline
+    done
+  done
+  unset DPC_CHUNK_SPARSE_ON
+fi
 if has bench; then
   B cfg2 --steps 50 --warmup 10
   B cfg2_driver --steps 20 --warmup 5 --no-cpu-baseline

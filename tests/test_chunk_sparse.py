@@ -79,8 +79,9 @@ def both_forms_agree_bit_for_bit(lib, dev, B, N, D, K, sigma, seed=7, Dz=-1):
     for a, b, name in zip(res[0], res[1], ("proj", "depth", "dpc", "dpose", "dscale")):
         if name in ("dpose", "dscale"):
             # (the per-view pose sums of several work-groups go through float atomics: two runs of the SAME form already
-            # differ in the last places, on the device and -- its threads are OS threads -- in the emulation)
-            assert np.abs(a - b).max() <= 3e-6 * max(np.abs(a).max(), 1e-30), (name, float(np.abs(a - b).max()))
+            # differ in the last places, on the device and -- its threads are OS threads -- in the emulation; the quaternion
+            # Jacobian then works on differences of those sums: 5e-6 of the largest component seen at 8000 points)
+            assert np.abs(a - b).max() <= 2e-5 * max(np.abs(a).max(), 1e-30), (name, float(np.abs(a - b).max()))
         else:
             assert np.array_equal(a, b), (name, float(np.abs(a - b).max()))
 
