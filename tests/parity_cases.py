@@ -117,6 +117,12 @@ FUSED_CASES_GPU = FUSED_CASES + [
     (2, 6000, 48, 48, 21, 3.0, True, True),      # 48 on 64 with 21 taps: dense gather flow on padded rows
     (1, 2000, 80, 80, 9, 1.4, False, False),     # 80 on 128 (10 of 16 lanes)
     (1, 3000, 160, 64, 7, 1.2, False, False),    # 160 on 256, shallow grid
+    # round 5: the tap counts beyond 21 (any odd pc_gauss_kernel_size is a legal configuration, default_config.yaml:55)
+    (1, 3000, 128, 128, 23, 4.0, False, False),
+    (2, 6000, 64, 64, 31, 5.0, True, False),     # widest compiled filter, dense gather flow
+    (1, 2000, 128, 64, 27, 4.5, False, True),    # vox_size_z = 64 at 128: Kz = 13
+    (1, 1500, 32, 32, 25, 4.2, False, False),    # 25 taps on 32-wide rows: the halo comes from 12 columns away
+    (1, 2500, 96, 96, 29, 4.8, False, False),    # padded rows
 ]
 DENSE_GATHER_CASE_EMU = (1, 3000, 32, 32, 5, 0.8, False, False)    # ~150+ points per occupied plane at D = 32
 

@@ -101,7 +101,7 @@ def test_emu_trimmed_filter_equals_the_full_one(emu, sigma):
         assert float((x - y).abs().max()) <= 2e-6 * max(1.0, float(y.abs().max())), sigma
 
 
-@pytest.mark.parametrize("K", [3, 7, 9, 13, 15, 17, 19])
+@pytest.mark.parametrize("K", [3, 7, 9, 13, 15, 17, 19, 23, 25, 27, 29, 31])
 def test_emu_new_tap_counts_match_the_numpy_oracle(emu, K):
     """Every tap count that gained compiled kernels this round (fused front / back end and z kernels), forward and
     backward against the float64 NumPy oracle."""
