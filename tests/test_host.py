@@ -66,7 +66,7 @@ def test_c_abi_argument_validation_without_gpu():
     assert lib.dpc_workspace_bytes(ctypes.byref(S), 0) % 256 == 0
     assert lib.dpc_saved_layout(ctypes.byref(S), ctypes.byref(P)) == 1      # D=8: generic path, dense grid_raw
     S64 = _capi.DpcShape(2, 10, 64, 64, 11, 11, 11)
-    # fused path: clip_mask + point_index; xy grid saved; 11 taps on 64-wide rows: chunk-sparse by the rule (K <= D/8 + 3)
+    # fused path: clip_mask + point_index; xy grid saved; 11 taps on 64-wide rows: chunk-sparse by the rule (64-wide rows: K <= D/8 + 5)
     assert lib.dpc_saved_layout(ctypes.byref(S64), ctypes.byref(P)) == 6 | 8 | 16
     assert lib.dpc_set_chunk_sparse(0) == -1 and lib.dpc_saved_layout(ctypes.byref(S64), ctypes.byref(P)) == 6 | 8
     assert lib.dpc_set_chunk_sparse(-1) == 0
