@@ -157,7 +157,7 @@ def plane_occupancy(case, k_run=None, chunk_sparse=False):
         cells = np.zeros(D + 1, dtype=bool)
         cells[iz[b][valid[b]]] = True
         live += int((cells[:D] | np.concatenate([[False], cells[:D - 1]])).sum())
-    chunks = None
+    chunks, chunks_g2 = None, 0
     if chunk_sparse:
         H = int(k_run if k_run is not None else case["K"]) // 2
         iy, ix = cell(1), cell(2)
@@ -173,8 +173,15 @@ def plane_occupancy(case, k_run=None, chunk_sparse=False):
                 for dz in (0, 1):
                     for c in (c_lo, c_hi):               # (2 H + 2 <= 32 columns: at most two chunks)
                         mark[z0[ok] + dz, y[ok], c[ok]] = True
-            chunks += int(mark[:D].sum())
-    return live, int(valid.sum()), chunks
+            mark = mark[:D]
+            chunks += int(mark.sum())
+            # G2 (saved for the backward pass under this layout): the marks widened by K/2 planes either way
+            wide = mark.copy()
+            for d in range(1, H + 1):
+                wide[d:] |= mark[:-d]
+                wide[:-d] |= mark[d:]
+            chunks_g2 += int(wide.sum())
+    return live, int(valid.sum()), chunks, (chunks_g2 if chunk_sparse else None)
 
 
 def kernel_bytes(label, case, save_xy, occ):
@@ -184,11 +191,14 @@ def kernel_bytes(label, case, save_xy, occ):
     plane = 4 * D * D
     L = occ[0] if occ else B * D                     # planes that exist
     img = B * plane                                  # one [B,D,D] image
+    LG = B * D                                       # planes of G2 (saved when the xy grid is not): dense
     if occ and len(occ) > 2 and occ[2] is not None:
         # chunk-sparse layout: of the occupied planes only the marked 128-byte chunks move (L in units of planes), plus the
-        # chunk marks themselves (a byte per row of an occupied plane, written twice by the splat, read once per consumer)
+        # chunk marks themselves (a byte per row of an occupied plane, written twice by the splat, read once per consumer);
+        # G2 is stored / read where a marked chunk lies within K/2 planes
         marks = L * D
         L = occ[2] * 128.0 / plane
+        LG = occ[3] * 128.0 / plane
     else:
         marks = 0
     fused = {
@@ -197,8 +207,8 @@ def kernel_bytes(label, case, save_xy, occ):
         # every point's record is read by the two planes it touches; 4 clip bytes per point; occupied planes out
         "splat_xy": (B * N * 32, L * plane + B * N * 4 + 2 * marks),
         # occupied planes in (+ all of G2 out at > 11 taps); proj, depth, loss gradient (+ its target in), fp64 sums
-        "zfwd": (L * plane + img + marks, (0 if save_xy else B * D * plane) + 3 * img + 4 * img),
-        "zbwd": ((L if save_xy else B * D) * plane + 4 * img + img + marks, L * plane),
+        "zfwd": (L * plane + img + marks, (0 if save_xy else LG * plane) + 3 * img + 4 * img),
+        "zbwd": ((L if save_xy else LG) * plane + 4 * img + img + marks, L * plane),
         # occupied planes + records + clip bytes in; 12-byte partials out (2 or 4 per point)
         "gather_yx": (L * plane + B * N * 32 + B * N * 4 + marks, B * N * 12 * (2 if D <= 64 else 4)),
         "points_bwd": (B * N * (12 * (2 if D <= 64 else 4) + 12 + 12 + 4), B * N * 12),
@@ -654,8 +664,8 @@ def main():
                 "kernel_bytes": {"read": rd, "written": wr,
                                  "basis": (("occupied planes of this run's clouds (%d of %d)%s + point records + images"
                                             % (occ[0], case["B"] * case["D"],
-                                               (", of which the marked 128-byte chunks (%d of %d: chunk-sparse layout) and their marks"
-                                                % (occ[2], case["B"] * case["D"] ** 3 // 32)) if occ[2] is not None else ""))
+                                               (", of which the marked 128-byte chunks (%d of %d: chunk-sparse layout; G2: %d) and their marks"
+                                                % (occ[2], case["B"] * case["D"] ** 3 // 32, occ[3])) if occ[2] is not None else ""))
                                            if occ else "dense planes + point records + images")},
                 "chunk_sparse": bool(occ and occ[2] is not None),
                 "ceilings": ceil, "kernel_ceiling": kceil, "vs_ceiling": None if not kceil else ach / kceil,
