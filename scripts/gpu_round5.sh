@@ -13,6 +13,13 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 export TMPDIR=/tmp
 has() { [[ " $DO " == *" $1 "* ]]; }
 (rocm-smi --showproductname 2>&1 | head -12; lscpu | head -16; nproc; sha256sum differentiable-point-clouds_amd/csrc/libdpc_hip.so) > "$OUT/00_env.log" 2>&1
+if has tests; then
+  timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -x > "$OUT/01_pytest_gpu.log" 2>&1
+  RC=$?; echo "pytest exit $RC" | tee -a "$OUT/01_pytest_gpu.log"; tail -15 "$OUT/01_pytest_gpu.log"
+  if [ $RC -ne 0 ] && [ -n "$STOP_ON_FAIL" ]; then echo "tests failed: stopping (STOP_ON_FAIL)"; exit 1; fi
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/02_smoke.log" 2>&1
+  echo "smoke exit $?" | tee -a "$OUT/02_smoke.log"; tail -1 "$OUT/02_smoke.log"
+fi
 if has rccl; then
   # RCCL on the one GPU: a forced ONE-rank process group (backend nccl).  Tests first, then the kernel trace of the
   # recorded training step (GradBuckets' all-reduces inside the HIP graph) and of the eager DDP step.
@@ -35,12 +42,6 @@ if has rccl; then
     timeout 300 python scripts/rccl_capture_stress.py --records 40 --drain 0 > "$OUT/24_stress_nodrain_$i.log" 2>&1; echo "stress WITHOUT drain, run $i rc=$? (non-zero expected)"
   done
   python scripts/summarize_rccl.py "$OUT" > "$OUT/23_rccl_world1.txt" 2>&1; tail -60 "$OUT/23_rccl_world1.txt"
-fi
-if has tests; then
-  timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -x > "$OUT/01_pytest_gpu.log" 2>&1
-  echo "pytest exit $?" | tee -a "$OUT/01_pytest_gpu.log"; tail -15 "$OUT/01_pytest_gpu.log"
-  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/02_smoke.log" 2>&1
-  echo "smoke exit $?" | tee -a "$OUT/02_smoke.log"; tail -1 "$OUT/02_smoke.log"
 fi
 B() {  # name, bench args...
   NAME=$1; shift

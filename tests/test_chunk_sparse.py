@@ -49,8 +49,8 @@ def _forward_raw(lib, D, K, N, B=2, radius=0.2, dev="cpu", pc=None, pose=None, s
 
 
 def sparse_form_writes_fewer_chunks_and_the_same_images(lib, D, K, N, dev="cpu"):
-    """The saved grid, dense against sparse form.  Up to 19 taps it is the xy-blurred grid: what the sparse form stored must be
-    the dense form's values, what it skipped must be zeros there.  Beyond (21 taps ...) it is G2, in BOTH forms stored through
+    """The saved grid, dense against sparse form.  Up to 19 taps (21 on rows up to 128 wide) it is the xy-blurred grid: what the
+    sparse form stored must be the dense form's values, what it skipped must be zeros there.  Beyond it is G2, in BOTH forms stored through
     the mask 'within K/2 planes of a part of the xy grid that is there' (planes without mass nearby / chunks without a mark
     nearby): the stored part must agree, and the sparse form stores less."""
     assert lib.dpc_set_chunk_sparse(0) in (-1, 0, 1)
@@ -90,7 +90,7 @@ def both_forms_agree_bit_for_bit(lib, dev, B, N, D, K, sigma, seed=7, Dz=-1):
             assert np.array_equal(a, b), (name, float(np.abs(a - b).max()))
 
 
-@pytest.mark.parametrize("D,K,N", [(64, 5, 300), (128, 11, 400), (64, 21, 300)])
+@pytest.mark.parametrize("D,K,N", [(64, 5, 300), (128, 11, 400), (64, 21, 300), (64, 23, 300)])
 def test_emu_sparse_form_writes_fewer_chunks_and_the_same_images(lib, D, K, N):
     sparse_form_writes_fewer_chunks_and_the_same_images(lib, D, K, N)
 
@@ -119,13 +119,14 @@ def test_emu_reference_conventions_hold_in_both_forms(lib, mode):
 
 def test_bench_counts_the_chunks_the_kernels_mark(lib):
     """bench.py's byte model for the chunk-sparse layout counts marked chunks on the host (plane_occupancy): they must be the
-    chunks the kernels really store (the 128-byte chunks of a NaN-initialised saved grid that came back written) -- up to 19 taps
-    the saved grid is the xy-blurred one (k_splat_xy's marks), beyond it is G2 (those marks widened by K/2 planes)"""
+    chunks the kernels really store (the 128-byte chunks of a NaN-initialised saved grid that came back written) -- where the saved
+    grid is the xy-blurred one these are k_splat_xy's marks, where it is G2 those marks widened by K/2 planes"""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    for cid, D, K, N, sigma in ((97, 64, 5, 400, 0.9), (98, 32, 7, 300, 1.2), (99, 128, 11, 500, 1.6), (96, 64, 21, 300, 0.9)):
+    for cid, D, K, N, sigma in ((97, 64, 5, 400, 0.9), (98, 32, 7, 300, 1.2), (99, 128, 11, 500, 1.6), (96, 64, 21, 300, 0.9),
+                                (95, 64, 23, 300, 0.9)):
         dpc_amd.synthetic.CONFIGS[cid] = dict(B=2, N=N, D=D, K=K, sigma=sigma)
         case = bench.build_case(cid, None, torch.device("cpu"))
         lib.dpc_set_chunk_sparse(1)
@@ -133,7 +134,7 @@ def test_bench_counts_the_chunks_the_kernels_mark(lib):
         grid, _, _ = _forward_raw(lib, D, K, N, pc=case["pc"].detach(), pose=case["pose"].detach(), sigma=sigma)
         written = ~np.isnan(grid.reshape(2, D, D, D // 32, 32))
         assert np.all(written.all(-1) == written.any(-1))              # chunks are stored whole
-        expect = chunks if K <= 19 else chunks_g2
+        expect = chunks if lib.saves_xy(2, N, D, K) else chunks_g2          # (xy grid: up to 19 taps, 21 on rows <= 128 wide)
         assert int(written.any(-1).sum()) == expect, (D, K, int(written.any(-1).sum()), chunks, chunks_g2)
         assert chunks <= chunks_g2 < 2 * D * D * D // 32 and live <= 2 * D and nvalid <= 2 * N
 

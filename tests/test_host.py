@@ -76,7 +76,11 @@ def test_c_abi_argument_validation_without_gpu():
     S48 = _capi.DpcShape(2, 10, 48, 48, 5, 5, 5)                               # 48 on the 64-wide geometry: no chunk maps
     assert lib.dpc_point_index_ints(ctypes.byref(S48)) == 5 * 2 * 10 + 2 * 50 + 2 * 8
     S21 = _capi.DpcShape(2, 10, 64, 64, 21, 21, 21)
-    assert lib.dpc_saved_layout(ctypes.byref(S21), ctypes.byref(P)) == 6       # 21 taps: G2 is what is saved
+    assert lib.dpc_saved_layout(ctypes.byref(S21), ctypes.byref(P)) == 6 | 8   # 21 taps on rows up to 128 wide: still the xy grid
+    S23 = _capi.DpcShape(2, 10, 64, 64, 23, 23, 23)
+    assert lib.dpc_saved_layout(ctypes.byref(S23), ctypes.byref(P)) == 6       # beyond: G2 is what is saved (64-wide: dense layout)
+    W21 = _capi.DpcShape(1, 10, 32, 256, 21, 21, 21)
+    assert lib.dpc_saved_layout(ctypes.byref(W21), ctypes.byref(P)) == 6 | 16  # 21 taps on 256-wide rows: G2, chunk-sparse
     Sdeep = _capi.DpcShape(1, 10, 320, 32, 5, 5, 5)                            # Dz > 256: beyond the plane-occupancy words
     assert lib.dpc_saved_layout(ctypes.byref(Sdeep), ctypes.byref(P)) == 1
     assert lib.dpc_workspace_bytes(ctypes.byref(S), 1) >= 2 * g
