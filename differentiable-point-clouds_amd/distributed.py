@@ -152,24 +152,25 @@ def barrier(device=None):
 
 def drain_watchdog(seconds=None):
     """Give ProcessGroupNCCL's watchdog thread time to reap the works of the collectives issued so far; called after a
-    synchronize and BEFORE a HIP-graph capture that will hold collectives.  A precaution, not a proven fix:
+    synchronize and BEFORE a HIP-graph capture that will hold collectives.
 
     The very first run of this code under RCCL (round 5, one rank, `bench.py --config 3 --graph --force-dist`; log in
     profiles/r05/rccl_first_contact_abort.txt) was killed by the watchdog: its poll of a work's end event
     (WorkNCCL::isCompleted -> hipEventQuery) came back with hipErrorCapturedEvent ("operation not permitted on an event
-    last recorded in a capturing stream"), which ProcessGroupNCCL turns into std::terminate.  It has not been seen
-    again: 0 of 50 further runs of the same command (cold and warm MIOpen caches, with and without this pause, with
-    and without a collective between init and the first bucket all-reduce), 0 of 360 re-recordings of the training
-    step with an eager barrier right before each capture and this pause switched off (scripts/rccl_capture_stress.py),
-    and a probe that holds a capture open for 0.5 s around a collective -- with a completed-but-unreaped eager work in
-    the watchdog's list, and with the capture-time work itself -- passes in every variant
-    (scripts/rccl_capture_probe.py).  So neither "the watchdog polls an eager event whose stream has since been forked
-    into the capture" nor "works created during the capture are polled" reproduces it on demand; the one thing known
-    is that the query and a capture overlapped.  torch 2.10 no longer holds a capture back until the watchdog's list
-    is empty (the pending-event-query counter of earlier releases is gone) and exposes no call that waits for it;
-    pausing 2.5 poll periods (the watchdog sleeps 100 ms between polls) once everything issued has completed leaves
-    that list empty when the capture begins, which removes one of the two candidates at the price of 0.25 s per
-    recording.  DPC_WATCHDOG_DRAIN_S=0 switches it off."""
+    last recorded in a capturing stream"), which ProcessGroupNCCL turns into std::terminate.  It is rare and it is real:
+    WITHOUT this pause 2 aborts in ~60 process runs / ~850 recordings that were preceded by an eager collective (the
+    first bench run; scripts/rccl_capture_stress.py --drain 0 in the final evidence session, at its 5th recording: same
+    stack, profiles/r05/z_rccl_stress_nodrain.log); WITH it none in ~40 runs / ~400 recordings (every bench / test run
+    since, the stress runs with the default pause).  So a watchdog poll that overlaps a capture holding collectives is
+    the trigger.  What exactly it polls is not pinned down: probes that hold a capture open for 0.5 s around a collective
+    -- with a completed-but-unreaped eager work in the watchdog's list, and with the capture-time work itself -- pass
+    (scripts/rccl_capture_probe.py), so it is neither simply "an eager event whose stream has since been forked into
+    the capture" nor "works created during the capture are polled"; the collectives of the failing runs are issued from
+    the autograd thread (gradient hooks), the probes' from the capturing thread.  torch 2.10 no longer holds a capture
+    back until the watchdog's list is empty (the pending-event-query counter of earlier releases is gone) and exposes
+    no call that waits for it; pausing 2.5 poll periods (the watchdog sleeps 100 ms between polls) once everything
+    issued has completed leaves that list empty when the capture begins.  0.25 s per recording; DPC_WATCHDOG_DRAIN_S=0
+    switches it off."""
     if not active() or dist.get_backend() != "nccl":
         return
     if seconds is None:

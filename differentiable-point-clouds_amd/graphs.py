@@ -13,8 +13,9 @@ What the recipe has to get right (each item was a failure on a real box or is a 
 * ``capture_error_mode="thread_local"``: the RCCL watchdog thread queries events while this thread records, which
   the default (global) mode turns into a capture error;
 * the watchdog's list of outstanding works is given time to empty before the capture begins
-  (``distributed.drain_watchdog``): the first run under RCCL (round 5) was killed by a watchdog poll that came back
-  with hipErrorCapturedEvent; not reproduced in 50 runs and 360 re-recordings since -- a precaution, see there;
+  (``distributed.drain_watchdog``): without that, about one recording in several hundred dies in the watchdog thread
+  (hipErrorCapturedEvent from its event poll: the first run under RCCL in round 5, and the no-drain stress run of the
+  final evidence session); with it, none so far;
 * a capture that fails half way leaves the rank's streams in capture mode and its peers waiting inside a collective:
   with more than one rank the error is raised, not swallowed;
 * nothing may keep the autograd graph of an EARLIER eager call of the same leaves alive while the step is recorded (a

@@ -761,8 +761,9 @@ def test_bench_one_rank_rccl_training_step_ddp_and_recorded():
 
 def test_recording_beside_the_rccl_watchdog_survives_many_recordings():
     """25 recordings of a step that holds RCCL collectives beside the live watchdog thread, an eager barrier before each
-    (the first run under RCCL was killed by a watchdog poll that overlapped a capture -- distributed.drain_watchdog; this
-    is the regression test that recording and re-recording keep working, not a reproduction of that abort)."""
+    (without distributed.drain_watchdog about one recording in several hundred is killed by a watchdog poll that overlaps
+    the capture -- scripts/rccl_capture_stress.py --drain 0 shows it now and then; this is the regression test that
+    recording and re-recording keep working with the pause in)."""
     import os
     import subprocess
     import sys
