@@ -157,20 +157,18 @@ def drain_watchdog(seconds=None):
     The very first run of this code under RCCL (round 5, one rank, `bench.py --config 3 --graph --force-dist`; log in
     profiles/r05/rccl_first_contact_abort.txt) was killed by the watchdog: its poll of a work's end event
     (WorkNCCL::isCompleted -> hipEventQuery) came back with hipErrorCapturedEvent ("operation not permitted on an event
-    last recorded in a capturing stream"), which ProcessGroupNCCL turns into std::terminate.  It is rare and it is real:
-    WITHOUT this pause 2 aborts in ~60 process runs / ~850 recordings that were preceded by an eager collective (the
-    first bench run; scripts/rccl_capture_stress.py --drain 0 in the final evidence session, at its 5th recording: same
-    stack, profiles/r05/z_rccl_stress_nodrain.log); WITH it none in ~40 runs / ~400 recordings (every bench / test run
-    since, the stress runs with the default pause).  So a watchdog poll that overlaps a capture holding collectives is
-    the trigger.  What exactly it polls is not pinned down: probes that hold a capture open for 0.5 s around a collective
-    -- with a completed-but-unreaped eager work in the watchdog's list, and with the capture-time work itself -- pass
-    (scripts/rccl_capture_probe.py), so it is neither simply "an eager event whose stream has since been forked into
-    the capture" nor "works created during the capture are polled"; the collectives of the failing runs are issued from
-    the autograd thread (gradient hooks), the probes' from the capturing thread.  torch 2.10 no longer holds a capture
-    back until the watchdog's list is empty (the pending-event-query counter of earlier releases is gone) and exposes
-    no call that waits for it; pausing 2.5 poll periods (the watchdog sleeps 100 ms between polls) once everything
-    issued has completed leaves that list empty when the capture begins.  0.25 s per recording; DPC_WATCHDOG_DRAIN_S=0
-    switches it off."""
+    last recorded in a capturing stream"), which ProcessGroupNCCL turns into std::terminate.  Hunted down with numbers
+    (profiles/r05/rccl_abort_hunt.txt): without this pause 5 of 16 stress processes died, every one within the first
+    ~130 ms after the burst of eager collectives of the warm-up -- also when no eager collective at all is issued
+    between the recordings -- and none later in ~10 000 recordings; with it, none in ~45 processes.  The watchdog reaps
+    completed works at its 100 ms cadence; for about that long its list still holds EAGER works whose end events were
+    recorded on RCCL's stream; a capture that holds a collective forks that very stream into the capture; a poll that
+    lands inside the capture queries an event whose stream is capturing at that moment, and HIP answers
+    hipErrorCapturedEvent (CUDA looks at the event itself, which was recorded eagerly).  torch 2.10 no longer holds a
+    capture back until the watchdog's list is empty (the pending-event-query counter of earlier releases is gone) and
+    exposes no call that waits for it: everything issued so far has completed (the caller synchronised), the next
+    poll removes it, and 2.5 poll periods are waited for here.  0.25 s per recording; DPC_WATCHDOG_DRAIN_S=0 switches
+    it off (scripts/rccl_capture_stress.py --drain 0 shows the abort)."""
     if not active() or dist.get_backend() != "nccl":
         return
     if seconds is None:

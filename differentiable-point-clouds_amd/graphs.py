@@ -13,9 +13,9 @@ What the recipe has to get right (each item was a failure on a real box or is a 
 * ``capture_error_mode="thread_local"``: the RCCL watchdog thread queries events while this thread records, which
   the default (global) mode turns into a capture error;
 * the watchdog's list of outstanding works is given time to empty before the capture begins
-  (``distributed.drain_watchdog``): without that, about one recording in several hundred dies in the watchdog thread
-  (hipErrorCapturedEvent from its event poll: the first run under RCCL in round 5, and the no-drain stress run of the
-  final evidence session); with it, none so far;
+  (``distributed.drain_watchdog``): for ~100 ms after a burst of eager collectives the watchdog still polls their end
+  events, and HIP rejects that query (hipErrorCapturedEvent -> std::terminate) if it lands while a capture holds RCCL's
+  stream -- the first run under RCCL in round 5 died that way, 5 of 16 stress processes without the pause, none with it;
 * a capture that fails half way leaves the rank's streams in capture mode and its peers waiting inside a collective:
   with more than one rank the error is raised, not swallowed;
 * nothing may keep the autograd graph of an EARLIER eager call of the same leaves alive while the step is recorded (a

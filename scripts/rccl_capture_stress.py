@@ -27,6 +27,14 @@ def main():
                     help="mlp: twelve linear layers (a capture of ~1 ms); train: the chair_unsupervised training step "
                          "(~250 launches, a capture of ~7 ms: the window the first RCCL run of round 5 died in)")
     ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--no-barrier", action="store_true",
+                    help="no eager collective before each recording (nothing of this script's is left in the watchdog's list)")
+    ap.add_argument("--main-thread", action="store_true",
+                    help="issue the bucket collectives from the capturing thread (in finish()) instead of from the "
+                         "gradient hooks on the autograd thread")
+    ap.add_argument("--pause-ms", type=float, default=0.0,
+                    help="sleep this long between the eager barrier and the recording (moves the phase of the watchdog's "
+                         "100 ms poll against the capture)")
     args = ap.parse_args()
     if args.drain is not None:
         os.environ["DPC_WATCHDOG_DRAIN_S"] = str(args.drain)
@@ -57,20 +65,34 @@ def main():
         inputs = ts.synthetic_batch(cfg, dev, 128, seed=0)
         projector.enable_graph_replay(follow_tap_counts=True)
         run = lambda: ts.train_step(net, projector, inputs, opt, world, buckets=red)
+    if args.main_thread:
+        # the hooks never see a complete bucket: finish() (capturing thread) issues every collective
+        def arm():
+            for i in range(len(red.buckets)):
+                red._pending[i] = 1 << 30
+            red._next = 0
+        red._arm = arm
+        arm()
     t0 = time.perf_counter()
     step = dpc_amd.graphs.RecordedStep(run, world=world, device=dev, collectives=True)
     for i in range(args.records - 1):
         for _ in range(5):
             step()
-        dd.barrier(dev)                  # an eager collective: its work sits in the watchdog's list for up to 100 ms
+        if not args.no_barrier:
+            dd.barrier(dev)              # an eager collective: its work sits in the watchdog's list for up to 100 ms
+        if args.pause_ms > 0:
+            time.sleep(args.pause_ms * 1e-3)
         sys.stderr.write("[stress] recording %d\n" % (i + 2))
+        if args.no_barrier:              # (RecordedStep._record itself issues a barrier when the step holds collectives)
+            step.collectives = False
         step._record()
     for _ in range(5):
         step()
     torch.cuda.synchronize()
-    print("OK: %d recordings of a step with %d bucket collectives, drain %s s, %.1f s [%s]" % (
-        step.records, len(red.buckets), os.environ.get("DPC_WATCHDOG_DRAIN_S", "0.25"), time.perf_counter() - t0,
-        dd.collective_library()), flush=True)
+    print("OK: %d recordings of a step with %d bucket collectives, drain %s s%s%s, %.1f s [%s]" % (
+        step.records, len(red.buckets), os.environ.get("DPC_WATCHDOG_DRAIN_S", "0.25"),
+        ", no eager barrier" if args.no_barrier else "", ", collectives from the capturing thread" if args.main_thread else "",
+        time.perf_counter() - t0, dd.collective_library()), flush=True)
     dd.finalize()
 
 
