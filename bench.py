@@ -539,7 +539,7 @@ def main():
         # count, barrier before the capture, thread-local capture mode, re-record when the blur's tap count moves).
         try:
             recorded = dpc_amd.graphs.RecordedStep(case["run"], world=world, device=device, collectives=dist_on,
-                                                   key=case["projector"].effective_tap_counts)
+                                                   key=case["projector"].recording_key)
             run = recorded
         except Exception as e:                       # noqa: BLE001
             # A capture that dies half way leaves the rank's streams in capture mode (seen with gloo on CUDA tensors,

@@ -149,6 +149,18 @@ class ModelPointCloud(object):
         from .util.point_cloud import effective_tap_counts
         return effective_tap_counts(self.cfg(), self._gauss_kernel, self._device)
 
+    def _gt_filter_on(self):
+        """model_pc.py:398-404: the GT masks are blurred like the prediction -- unless pc_gauss_filter_gt_switch_off and the
+        annealed sigma has fallen below 1"""
+        cfg = self.cfg()
+        return bool(cfg.pc_gauss_filter_gt) and not (cfg.pc_gauss_filter_gt_switch_off and self._sigma_rel < 1.0)
+
+    def recording_key(self):
+        """Everything a recorded step (HIP graph) has frozen that the schedules can move: the blur's effective tap counts
+        and whether the GT filter is still on.  dpc_amd.graphs.RecordedStep(run, key=projector.recording_key) records the
+        step again when it changes."""
+        return (self.effective_tap_counts(), self._gt_filter_on())
+
     def setup_misc(self, generator=None):                     # model_pc.py:161-168
         """Reference cloud of the pose_student_align_loss: 2000 points ~ N(0,1) clipped to +-3
         (a tf.Variable there; assign `_pc_for_alignloss` to share one across ranks)."""
@@ -417,15 +429,15 @@ class ModelPointCloud(object):
             gt = resize_images_bicubic_tf1(gt, [pred_size, pred_size])
             gt_size = pred_size
         if cfg.pc_gauss_filter_gt:                                          # model_pc.py:398-404
-            if getattr(self, "_graph_replay", False):
-                # the GT blur takes sigma as a host number and a host branch on it: a recorded step would freeze both
-                raise NotImplementedError("graph replay with pc_gauss_filter_gt (the annealed sigma reaches the GT "
-                                          "blur as a host scalar)")
             if gt_size > pred_size:
                 gt = resize_images_bilinear_tf1(gt, [pred_size, pred_size])
-            smoothed = gauss_smoothen_image(cfg, gt, self._sigma_rel)
-            if not (cfg.pc_gauss_filter_gt_switch_off and self._sigma_rel < 1.0):
-                gt = smoothed
+            if self._gt_filter_on():
+                # Replayed as a HIP graph, the taps come from the projector's own x filter -- the same gauss_kernel_1d(K,
+                # sigma) (gauss_kernel.py:5-11,27-32), living at a fixed address that set_global_step overwrites in place;
+                # the switch-off branch (a host decision on sigma) is part of recording_key(): the step is recorded again
+                # when it flips.
+                taps = self._gauss_kernel[0] if getattr(self, "_graph_replay", False) else None
+                gt = gauss_smoothen_image(cfg, gt, self._sigma_rel, kernel=taps)
         total_loss = 0
         # otherwise the bilinear GT resize (model_pc.py:392-397) happens inside the loss kernel
         fused = outputs.get("_fused_proj_loss")

@@ -56,11 +56,15 @@ def gauss_kernel_1d(l, sig, device=None):
     return kernel
 
 
-def gauss_smoothen_image(cfg, img, sigma_rel):
+def gauss_smoothen_image(cfg, img, sigma_rel, kernel=None):
     """dpc/util/gauss_kernel.py:14-24: per-channel separable blur of [B,H,W,C] images, SAME zero
-    padding (GT masks / images only; a few launches of stock depthwise conv on small tensors)."""
+    padding (GT masks / images only; a few launches of stock depthwise conv on small tensors).
+    `kernel`: the 1-D taps as a device tensor instead of a sigma -- a step replayed as a HIP graph reads them from a
+    buffer at a fixed address that the sigma schedule overwrites in place (ModelPointCloud.enable_graph_replay)."""
     fsz = int(cfg.pc_gauss_kernel_size)
-    kernel = gauss_kernel_1d(fsz, sigma_rel, img.device).to(img.dtype)
+    if kernel is None:
+        kernel = gauss_kernel_1d(fsz, sigma_rel, img.device)
+    kernel = kernel.reshape(-1).to(img.dtype)
     c = img.shape[-1]
     x = img.permute(0, 3, 1, 2)
     x = torch.nn.functional.conv2d(x, kernel.reshape(1, 1, 1, fsz).repeat(c, 1, 1, 1), padding=(0, fsz // 2), groups=c)

@@ -119,7 +119,7 @@ def main():
         # new recording whenever the annealed blur moves on to a smaller tap count
         projector.enable_graph_replay(follow_tap_counts=True)
         run = dpc_amd.graphs.RecordedStep(run, world=world, device=device, collectives=dist_on,
-                                             key=projector.effective_tap_counts)
+                                             key=projector.recording_key)
     step = 0
     for _ in range(args.warmup):
         projector.set_global_step(step)          # sigma / dropout schedules (in place under --graph)

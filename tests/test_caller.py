@@ -203,3 +203,74 @@ def test_student_align_loss_matches_reference(emu):
     assert abs(float(loss) - float(g["align_loss_f64"])) < 1e-4 * float(g["align_loss_f64"])
     assert relerr(stud.grad.numpy(), g["align_dstudent_f64"]) < 1e-4
     assert relerr(poses.grad.numpy(), g["align_dposes_f64"]) < 2e-4
+
+
+def test_gt_filter_taps_from_the_projectors_x_filter():
+    """model_pc.py:398-404 under graph replay: the GT blur takes its taps from the projector's x filter (the same
+    gauss_kernel_1d(K, sigma), gauss_kernel.py:27-32) instead of a host sigma -- same bits; and recording_key() carries what a
+    recorded step froze: the tap counts and whether the GT filter is still on (pc_gauss_filter_gt_switch_off: off below sigma 1)."""
+    import dpc_amd
+    from dpc_amd.util.gauss_kernel import gauss_smoothen_image
+    cfg = dpc_amd.default_config(vox_size=32, pc_gauss_kernel_size=11, pc_relative_sigma=2.0, pc_relative_sigma_end=0.5,
+                                 max_number_of_steps=10, pc_gauss_filter_gt=True, pc_gauss_filter_gt_switch_off=True)
+    img = torch.rand(3, 32, 32, 1)
+    for sigma in (2.0, 1.3, 0.7):
+        a = gauss_smoothen_image(cfg, img, sigma)
+        b = gauss_smoothen_image(cfg, img, None, kernel=dpc_amd.smoothing_kernel(cfg, sigma, device="cpu")[0])
+        assert torch.equal(a, b)
+    m = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device="cpu")
+    keys = []
+    for gs in range(0, 11):
+        m.set_global_step(gs)
+        keys.append(m.recording_key())
+        assert keys[-1][1] == (dpc_amd.model_pc.get_smooth_sigma(cfg, gs) >= 1.0)
+    assert keys[0][1] is True and keys[-1][1] is False
+    cfg2 = dpc_amd.default_config(vox_size=32, pc_gauss_kernel_size=11, pc_gauss_filter_gt=True)
+    m2 = dpc_amd.model_pc.ModelPointCloud(cfg2, global_step=0, device="cpu")
+    assert m2.recording_key() == (m2.effective_tap_counts(), True)
+
+
+@pytest.mark.gpu
+def test_gt_filter_under_graph_replay_gpu():
+    """cfg.pc_gauss_filter_gt (+ switch_off) with the step replayed as a HIP graph: the loss and the gradient of the recorded
+    step equal the eager ones at every step of a sigma schedule that crosses 1.0 (round 4 raised NotImplementedError here)."""
+    import dpc_amd
+    dev = torch.device("cuda")
+    dpc_amd._capi.set_library(None)
+    kw = dict(vox_size=32, pc_gauss_kernel_size=11, pc_relative_sigma=2.0, pc_relative_sigma_end=0.5, max_number_of_steps=12,
+              pc_gauss_filter_gt=True, pc_gauss_filter_gt_switch_off=True, pose_predict_num_candidates=1, predict_pose=True,
+              step_size=1, batch_size=4, pc_num_points=500, pc_point_dropout=1.0, pc_point_dropout_scheduled=False,
+              pose_predictor_student=False)
+    cfg = dpc_amd.default_config(**kw)
+    rng = np.random.default_rng(3)
+    pts = torch.tensor((0.25 * rng.standard_normal((4, 500, 3))).clip(-0.45, 0.45).astype(np.float32), device=dev, requires_grad=True)
+    poses = torch.tensor(rng.standard_normal((4, 4)).astype(np.float32), device=dev)
+    masks = torch.tensor((rng.random((4, 64, 64, 1)) > 0.5).astype(np.float32), device=dev)
+    inputs = {"masks": masks}
+
+    def make():
+        return dpc_amd.model_pc.ModelPointCloud(dpc_amd.default_config(**kw), global_step=0, device=dev)
+
+    def step_of(m):
+        def run():
+            out = {"points_1": pts, "all_points": pts, "poses": poses, "all_scaling_factors": None, "scaling_factor": None,
+                   "all_rgb": None, "all_focal_length": None, "predicted_translation": None}
+            out = m.compute_projection(inputs, out, is_training=True)
+            loss = m.add_proj_loss(inputs, out, 1.0)
+            g, = torch.autograd.grad(loss, [pts])
+            return loss.detach(), g
+        return run
+    eager = make()
+    rec = make()
+    rec.enable_graph_replay(follow_tap_counts=True)
+    step = dpc_amd.graphs.RecordedStep(step_of(rec), world=1, device=dev, key=rec.recording_key)
+    flips = set()
+    for gs in range(0, 13):
+        eager.set_global_step(gs)
+        rec.set_global_step(gs)
+        l0, g0 = step_of(eager)()
+        l1, g1 = step()
+        flips.add(rec.recording_key()[1])
+        assert abs(float(l0) - float(l1)) <= 1e-6 * abs(float(l0)), (gs, float(l0), float(l1))
+        assert float((g0 - g1).abs().max()) <= 1e-6 * float(g0.abs().max()), gs
+    assert flips == {True, False} and step.records >= 2
