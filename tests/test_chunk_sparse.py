@@ -108,13 +108,15 @@ def test_emu_both_forms_agree_on_a_256_wide_grid(lib):
 
 @pytest.mark.parametrize("mode", [0, 1])
 def test_emu_reference_conventions_hold_in_both_forms(lib, mode):
-    """knife edges (corner cells of weight exactly 0 still carry a gradient: the chunk flags are geometry, not values), dropout,
-    the fused loss, a dense-gather plane -- with the layout forced either way"""
+    """knife edges (corner cells of weight exactly 0 still carry a gradient: the chunk flags are geometry, not values) with the
+    layout forced either way; forced sparse also dropout, the fused loss, a dense-gather plane (the dense form of those is what
+    the other emulation tests run wherever the rule says so)"""
     lib.dpc_set_chunk_sparse(mode)
     parity_cases.knife_edge_inputs_match_reference_conventions("cpu", 32, 33)
-    parity_cases.fused_dropout_equals_explicit_subset("cpu", extras=False)
-    parity_cases.fused_candidate_loss_equals_the_image_epilogue("cpu", N=100)
-    parity_cases.fused_path_against_numpy_oracle("cpu", *parity_cases.DENSE_GATHER_CASE_EMU)
+    if mode == 1:
+        parity_cases.fused_dropout_equals_explicit_subset("cpu", extras=False)
+        parity_cases.fused_candidate_loss_equals_the_image_epilogue("cpu", N=100)
+        parity_cases.fused_path_against_numpy_oracle("cpu", *parity_cases.DENSE_GATHER_CASE_EMU)
 
 
 def test_bench_counts_the_chunks_the_kernels_mark(lib):
@@ -125,8 +127,7 @@ def test_bench_counts_the_chunks_the_kernels_mark(lib):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    for cid, D, K, N, sigma in ((97, 64, 5, 400, 0.9), (98, 32, 7, 300, 1.2), (99, 128, 11, 500, 1.6), (96, 64, 21, 300, 0.9),
-                                (95, 64, 23, 300, 0.9)):
+    for cid, D, K, N, sigma in ((97, 64, 5, 300, 0.9), (98, 32, 7, 200, 1.2), (95, 64, 23, 200, 0.9)):
         dpc_amd.synthetic.CONFIGS[cid] = dict(B=2, N=N, D=D, K=K, sigma=sigma)
         case = bench.build_case(cid, None, torch.device("cpu"))
         lib.dpc_set_chunk_sparse(1)
