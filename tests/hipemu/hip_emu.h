@@ -7,12 +7,14 @@
 // not a fallback: the product loader only ever opens libdpc_hip.so; this
 // library is built into tests/hipemu/ and opened only by tests (-m "not gpu").
 //
-// Model: blocks run one after another; the threads of a block are real OS
-// threads (so __syncthreads, LDS sharing and atomics behave like the real
-// thing); `__shared__` becomes a function-local static shared by those
-// threads; wave shuffles are emulated through a per-block exchange buffer and
-// therefore must be called in block-uniform control flow (which the kernels
-// guarantee).  Wavefront width is 64, as on gfx950.
+// Model (round 5: fibers; rounds 1-4 ran every lane as an OS thread and spent six times the kernels' own time in futex
+// calls): the threads of a block are user-space fibers (ucontext) of ONE OS thread, switched at the block's synchronisation
+// points only -- __syncthreads and the per-wavefront rendezvous of shuffles / ballots / DPP moves -- in lane order, so a run
+// is deterministic within a block; `__shared__` becomes a function-local `static thread_local`, i.e. one copy per OS
+// thread = per block in flight; a launch's blocks are dealt round-robin to a small pool of OS threads (DPC_EMU_THREADS,
+// default min(8, cores)) and run one after another on each, so atomics on global memory meet real concurrency between
+// blocks, as on the GPU.  Wave shuffles go through a per-block exchange buffer and rendezvous per WAVE: they may sit in
+// wave-uniform (not necessarily block-uniform) control flow.  Wavefront width is 64, as on gfx950.
 #pragma once
 #include <pthread.h>
 #include <stdint.h>
@@ -43,7 +45,7 @@ typedef int hipError_t;
 #define __device__
 #define __host__
 #define __forceinline__ inline
-#define __shared__ static
+#define __shared__ static thread_local
 #define __launch_bounds__(...)
 
 namespace hipemu {
@@ -51,31 +53,35 @@ struct Ctx {
   dim3 tid, bid, bdim, gdim;
   unsigned flat;  // flat thread index in block
 };
-extern thread_local Ctx t_ctx;
-extern pthread_barrier_t* g_barrier;
-extern unsigned char* g_dyn_smem;
-extern unsigned int* g_xchg;   // per-thread 32-bit exchange words for shuffles
-extern pthread_barrier_t* g_wave_barriers;  // one per wave64 of the block
+// the block this OS thread is running (hip_emu.cpp)
+struct Block {
+  unsigned nthreads;
+  unsigned char* dyn_smem;
+  unsigned int* xchg;      // per-thread 32-bit exchange words for shuffles
+  int vote;
+};
+extern thread_local Ctx* t_ctxp;       // the fiber that is running on this OS thread
+extern thread_local Block* t_block;
+inline Ctx& cur() { return *t_ctxp; }
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
-inline void sync() { pthread_barrier_wait(g_barrier); }
-inline void wave_sync() { pthread_barrier_wait(&g_wave_barriers[t_ctx.flat >> 6]); }
+void sync();        // all fibers of the block
+void wave_sync();   // the (up to) 64 fibers of the caller's wavefront
 }  // namespace hipemu
 
-#define threadIdx (hipemu::t_ctx.tid)
-#define blockIdx (hipemu::t_ctx.bid)
-#define blockDim (hipemu::t_ctx.bdim)
-#define gridDim (hipemu::t_ctx.gdim)
+#define threadIdx (hipemu::cur().tid)
+#define blockIdx (hipemu::cur().bid)
+#define blockDim (hipemu::cur().bdim)
+#define gridDim (hipemu::cur().gdim)
 
 static inline void __syncthreads() { hipemu::sync(); }
 
-namespace hipemu { extern int g_vote; }
 static inline int __syncthreads_or(int pred) {
   hipemu::sync();
-  if (hipemu::t_ctx.flat == 0) __atomic_store_n(&hipemu::g_vote, 0, __ATOMIC_RELAXED);
+  if (hipemu::cur().flat == 0) __atomic_store_n(&hipemu::t_block->vote, 0, __ATOMIC_RELAXED);
   hipemu::sync();
-  if (pred) __atomic_store_n(&hipemu::g_vote, 1, __ATOMIC_RELAXED);
+  if (pred) __atomic_store_n(&hipemu::t_block->vote, 1, __ATOMIC_RELAXED);
   hipemu::sync();
-  const int r = __atomic_load_n(&hipemu::g_vote, __ATOMIC_RELAXED);
+  const int r = __atomic_load_n(&hipemu::t_block->vote, __ATOMIC_RELAXED);
   hipemu::sync();
   return r;
 }
@@ -105,61 +111,61 @@ static inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch
 // they may sit in wave-uniform (not necessarily block-uniform) control flow, as on the GPU
 static inline float __shfl_down(float v, unsigned delta, int width = 64) {
   (void)width;
-  unsigned f = hipemu::t_ctx.flat;
-  memcpy(&hipemu::g_xchg[f], &v, 4);
+  unsigned f = hipemu::cur().flat;
+  memcpy(&hipemu::t_block->xchg[f], &v, 4);
   hipemu::wave_sync();
   unsigned lane = f & 63u;
-  unsigned nthreads = hipemu::t_ctx.bdim.x * hipemu::t_ctx.bdim.y * hipemu::t_ctx.bdim.z;
+  unsigned nthreads = hipemu::cur().bdim.x * hipemu::cur().bdim.y * hipemu::cur().bdim.z;
   float r = v;
-  if (lane + delta < 64u && f + delta < nthreads) memcpy(&r, &hipemu::g_xchg[f + delta], 4);
+  if (lane + delta < 64u && f + delta < nthreads) memcpy(&r, &hipemu::t_block->xchg[f + delta], 4);
   hipemu::wave_sync();
   return r;
 }
 static inline unsigned long long __ballot(int pred) {
-  unsigned f = hipemu::t_ctx.flat;
-  hipemu::g_xchg[f] = pred ? 1u : 0u;
+  unsigned f = hipemu::cur().flat;
+  hipemu::t_block->xchg[f] = pred ? 1u : 0u;
   hipemu::wave_sync();
-  unsigned nthreads = hipemu::t_ctx.bdim.x * hipemu::t_ctx.bdim.y * hipemu::t_ctx.bdim.z;
+  unsigned nthreads = hipemu::cur().bdim.x * hipemu::cur().bdim.y * hipemu::cur().bdim.z;
   unsigned base = f & ~63u;
   unsigned long long r = 0;
   for (unsigned i = 0; i < 64u && base + i < nthreads; ++i)
-    if (hipemu::g_xchg[base + i]) r |= 1ull << i;
+    if (hipemu::t_block->xchg[base + i]) r |= 1ull << i;
   hipemu::wave_sync();
   return r;
 }
 // wave-level vote (block-uniform control flow only, like the shuffles)
 static inline int __any(int pred) {
-  unsigned f = hipemu::t_ctx.flat;
-  hipemu::g_xchg[f] = pred ? 1u : 0u;
+  unsigned f = hipemu::cur().flat;
+  hipemu::t_block->xchg[f] = pred ? 1u : 0u;
   hipemu::wave_sync();
-  unsigned nthreads = hipemu::t_ctx.bdim.x * hipemu::t_ctx.bdim.y * hipemu::t_ctx.bdim.z;
+  unsigned nthreads = hipemu::cur().bdim.x * hipemu::cur().bdim.y * hipemu::cur().bdim.z;
   unsigned base = f & ~63u;
   int r = 0;
-  for (unsigned i = base; i < base + 64u && i < nthreads; ++i) r |= (int)hipemu::g_xchg[i];
+  for (unsigned i = base; i < base + 64u && i < nthreads; ++i) r |= (int)hipemu::t_block->xchg[i];
   hipemu::wave_sync();
   return r;
 }
 static inline float __shfl(float v, int src_lane, int width = 64) {
   (void)width;
-  unsigned f = hipemu::t_ctx.flat;
-  memcpy(&hipemu::g_xchg[f], &v, 4);
+  unsigned f = hipemu::cur().flat;
+  memcpy(&hipemu::t_block->xchg[f], &v, 4);
   hipemu::wave_sync();
-  unsigned nthreads = hipemu::t_ctx.bdim.x * hipemu::t_ctx.bdim.y * hipemu::t_ctx.bdim.z;
+  unsigned nthreads = hipemu::cur().bdim.x * hipemu::cur().bdim.y * hipemu::cur().bdim.z;
   unsigned src = (f & ~63u) | ((unsigned)src_lane & 63u);
   float r = v;
-  if (src < nthreads) memcpy(&r, &hipemu::g_xchg[src], 4);
+  if (src < nthreads) memcpy(&r, &hipemu::t_block->xchg[src], 4);
   hipemu::wave_sync();
   return r;
 }
 static inline float __shfl_xor(float v, int mask, int width = 64) {
   (void)width;
-  unsigned f = hipemu::t_ctx.flat;
-  memcpy(&hipemu::g_xchg[f], &v, 4);
+  unsigned f = hipemu::cur().flat;
+  memcpy(&hipemu::t_block->xchg[f], &v, 4);
   hipemu::wave_sync();
-  unsigned nthreads = hipemu::t_ctx.bdim.x * hipemu::t_ctx.bdim.y * hipemu::t_ctx.bdim.z;
+  unsigned nthreads = hipemu::cur().bdim.x * hipemu::cur().bdim.y * hipemu::cur().bdim.z;
   unsigned src = (f & ~63u) | ((f & 63u) ^ (unsigned)mask);
   float r = v;
-  if (src < nthreads) memcpy(&r, &hipemu::g_xchg[src], 4);
+  if (src < nthreads) memcpy(&r, &hipemu::t_block->xchg[src], 4);
   hipemu::wave_sync();
   return r;
 }
@@ -170,8 +176,8 @@ static inline float __shfl_xor(float v, int mask, int width = 64) {
 // its row gets 0 (bound_ctrl) or keeps `old`.  Lane mapping verified on MI355X (scripts/ubench/dpp_check.hip).
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   (void)bank_mask;
-  unsigned f = hipemu::t_ctx.flat;
-  memcpy(&hipemu::g_xchg[f], &src, 4);
+  unsigned f = hipemu::cur().flat;
+  memcpy(&hipemu::t_block->xchg[f], &src, 4);
   hipemu::wave_sync();
   const int lane = (int)(f & 63u), r = lane & 15, row = lane >> 4;
   int from = -1;
@@ -180,10 +186,10 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
   else if (ctrl == 0x142) from = row >= 1 ? 16 * row - 1 : -1;     // row_bcast:15: lane 15 of the previous row
   else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;               // row_bcast:31: lane 31 to rows 2 and 3
   else abort();
-  unsigned nthreads = hipemu::t_ctx.bdim.x * hipemu::t_ctx.bdim.y * hipemu::t_ctx.bdim.z;
+  unsigned nthreads = hipemu::cur().bdim.x * hipemu::cur().bdim.y * hipemu::cur().bdim.z;
   int res = bound_ctrl ? 0 : old;
   if (!((row_mask >> row) & 1)) from = -1, res = old;              // rows outside row_mask keep `old`
-  if (from >= 0 && (f & ~63u) + (unsigned)from < nthreads) memcpy(&res, &hipemu::g_xchg[(f & ~63u) + (unsigned)from], 4);
+  if (from >= 0 && (f & ~63u) + (unsigned)from < nthreads) memcpy(&res, &hipemu::t_block->xchg[(f & ~63u) + (unsigned)from], 4);
   hipemu::wave_sync();
   return res;
 }
@@ -221,7 +227,7 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
   } while (0)
 
 // HIP's own spelling of `extern __shared__ type var[];`
-#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::g_dyn_smem);
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::t_block->dyn_smem);
 
 // AMDGCN builtins used by the kernels
 static inline float __builtin_amdgcn_fmed3f(float v, float lo, float hi) { return fmaxf(fminf(v, hi), lo); }
