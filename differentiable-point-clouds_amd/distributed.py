@@ -52,7 +52,7 @@ def init(backend=None, device=None, force=None):
         kw = {"device_id": device} if device.type == "cuda" else {}
         with _stdout_to_stderr():     # RCCL prints a version banner on STDOUT when its first communicator comes up;
             dist.init_process_group(backend, rank=rank, world_size=world, **kw)      # stdout is for the ONE JSON line
-            if backend == "nccl" and os.environ.get("DPC_INIT_BARRIER", "1") == "1":
+            if backend == "nccl" and os.environ.get("DPC_INIT_BARRIER", "1") == "1":      # (0: dev, scripts/dev_r05)
                 dist.barrier()        # the communicator is created here at the latest
                 torch.cuda.synchronize(device)
     return rank, world, device

@@ -71,9 +71,6 @@ class RecordedStep(object):
     def _record(self):
         torch.cuda.synchronize(self.device)          # nothing of the previous recording is in flight any more ...
         self.graph, self.out = None, None            # ... before its memory pool is released
-        if os.environ.get("DPC_GC_BEFORE_CAPTURE") == "1":
-            import gc
-            gc.collect()
         if self.collectives:
             dd.barrier(self.device)
             dd.drain_watchdog()                      # (precaution: the watchdog's list is empty when the capture begins)

@@ -15,5 +15,5 @@ V nocache env TORCH_NCCL_CUDA_EVENT_CACHE=0
 V sum env DPC_BUCKET_AVG=0
 EXTRA="--burn-in 0" V noburn env
 EXTRA="--batch 4" V batch4 env
-V gc env DPC_GC_BEFORE_CAPTURE=1
+# (a variant that forced gc.collect() before the capture ran here too: no difference; the hook is gone)
 grep -h "GradBuckets\]" "$OUT/base.err" | sort | uniq -c | head -20
