@@ -157,18 +157,19 @@ def drain_watchdog(seconds=None):
     The very first run of this code under RCCL (round 5, one rank, `bench.py --config 3 --graph --force-dist`; log in
     profiles/r05/rccl_first_contact_abort.txt) was killed by the watchdog: its poll of a work's end event
     (WorkNCCL::isCompleted -> hipEventQuery) came back with hipErrorCapturedEvent ("operation not permitted on an event
-    last recorded in a capturing stream"), which ProcessGroupNCCL turns into std::terminate.  Hunted down with numbers
+    last recorded in a capturing stream"), which ProcessGroupNCCL turns into std::terminate.  What the hunt established
     (profiles/r05/rccl_abort_hunt.txt): without this pause 5 of 16 stress processes died, every one within the first
-    ~130 ms after the burst of eager collectives of the warm-up -- also when no eager collective at all is issued
-    between the recordings -- and none later in ~10 000 recordings; with it, none in ~45 processes.  The watchdog reaps
-    completed works at its 100 ms cadence; for about that long its list still holds EAGER works whose end events were
-    recorded on RCCL's stream; a capture that holds a collective forks that very stream into the capture; a poll that
-    lands inside the capture queries an event whose stream is capturing at that moment, and HIP answers
-    hipErrorCapturedEvent (CUDA looks at the event itself, which was recorded eagerly).  torch 2.10 no longer holds a
-    capture back until the watchdog's list is empty (the pending-event-query counter of earlier releases is gone) and
-    exposes no call that waits for it: everything issued so far has completed (the caller synchronised), the next
-    poll removes it, and 2.5 poll periods are waited for here.  0.25 s per recording; DPC_WATCHDOG_DRAIN_S=0 switches
-    it off (scripts/rccl_capture_stress.py --drain 0 shows the abort)."""
+    ~130 ms after the burst of eager collectives of the warm-up -- the time the watchdog (100 ms cadence) still holds
+    their works -- also when no eager collective at all is issued between the recordings, and none later in ~10 000
+    recordings; with it, none in ~60 processes / ~900 recordings.  So the collision needs leftover eager works in the
+    watchdog's list AND a capture that holds a collective AND a poll landing inside it; the pause removes the first.
+    The precise rule inside HIP is NOT established: probes that rebuild those ingredients from the capturing thread
+    alone (200 eager all-reduces, then at once a capture with a collective held open 0.3 s) pass every time; the
+    failing runs issue their collectives from the autograd engine's thread (gradient hooks), the eager ones on a side
+    stream.  torch 2.10 no longer holds a capture back until the watchdog's list is empty (the pending-event-query
+    counter of earlier releases is gone) and exposes no call that waits for it: everything issued so far has completed
+    (the caller synchronised), the next poll removes it, and 2.5 poll periods are waited for here.  0.25 s per
+    recording; DPC_WATCHDOG_DRAIN_S=0 switches it off (scripts/rccl_capture_stress.py --drain 0 shows the abort)."""
     if not active() or dist.get_backend() != "nccl":
         return
     if seconds is None:

@@ -8,6 +8,9 @@ The watchdog polls every 100 ms; every variant holds its window open for 0.5 s, 
   leftover_forked    eager barrier, capture begins at once, a collective, then 0.5 s inside the capture
   drained_forked     eager barrier, 0.3 s pause, capture, a collective, then 0.5 s inside the capture
   drained_waited     as drained_forked, but work.wait() before the pause (the communication stream has joined again)
+  burst_forked       200 eager all-reduces, a synchronize, then AT ONCE (raw capture_begin: no gc.collect in between) a capture
+                     with a collective, held open 0.3 s: the watchdog's list is certainly not empty when it polls inside
+  burst_unforked     the same, but the 0.3 s pass BEFORE the capture's collective (RCCL's stream not yet forked)
 """
 import os
 import sys
@@ -34,6 +37,29 @@ torch.cuda.synchronize()
 if variant.startswith("drained"):
     time.sleep(0.3)
 g = torch.cuda.CUDAGraph()
+if variant.startswith("burst"):
+    for _ in range(200):
+        dist.all_reduce(x, op=dist.ReduceOp.AVG)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        g.capture_begin(capture_error_mode="thread_local")
+        y = x * 2.0
+        if variant == "burst_unforked":
+            time.sleep(0.3)
+        w = dist.all_reduce(y, op=dist.ReduceOp.AVG, async_op=True)
+        if variant == "burst_forked":
+            time.sleep(0.3)
+        w.wait()
+        z = y + 1.0
+        g.capture_end()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    time.sleep(0.3)
+    print("PROBE", variant, "OK", flush=True)
+    dpc_amd.distributed.finalize()
+    sys.exit(0)
 with torch.cuda.graph(g, capture_error_mode="thread_local"):
     y = x * 2.0
     if variant == "leftover_unforked":
