@@ -11,6 +11,11 @@ The watchdog polls every 100 ms; every variant holds its window open for 0.5 s, 
   burst_forked       200 eager all-reduces, a synchronize, then AT ONCE (raw capture_begin: no gc.collect in between) a capture
                      with a collective, held open 0.3 s: the watchdog's list is certainly not empty when it polls inside
   burst_unforked     the same, but the 0.3 s pass BEFORE the capture's collective (RCCL's stream not yet forked)
+  burst_side_forked  burst_forked with the eager all-reduces issued (from the capturing thread) on a SIDE stream, like the warm-up
+  hooks_held         the stress scenario made certain: 20 eager steps whose bucket all-reduces are issued from GRADIENT HOOKS (the
+                     autograd engine's thread) on a side stream, a synchronize, then at once a capture of the same step (hooks
+                     again), held open 0.3 s
+  hooks_held_drained the same with 0.3 s between the eager steps and the capture (the watchdog's list is empty)
 """
 import os
 import sys
@@ -37,9 +42,49 @@ torch.cuda.synchronize()
 if variant.startswith("drained"):
     time.sleep(0.3)
 g = torch.cuda.CUDAGraph()
+if variant.startswith("hooks"):
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(*[torch.nn.Linear(1024, 1024) for _ in range(8)]).to(dev)
+    red = dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=8)
+    xin = torch.randn(256, 1024, device=dev)
+
+    def run():
+        red.zero_()
+        net(xin).square().mean().backward()
+        red.finish()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(20):
+            run()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    if variant == "hooks_held_drained":
+        time.sleep(0.3)
+    cap = torch.cuda.Stream()
+    with torch.cuda.stream(cap):
+        g.capture_begin(capture_error_mode="thread_local")
+        run()
+        time.sleep(0.3)
+        g.capture_end()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    time.sleep(0.3)
+    print("PROBE", variant, "OK (%d buckets)" % len(red.buckets), flush=True)
+    dpc_amd.distributed.finalize()
+    sys.exit(0)
 if variant.startswith("burst"):
-    for _ in range(200):
-        dist.all_reduce(x, op=dist.ReduceOp.AVG)
+    if variant == "burst_side_forked":
+        warm = torch.cuda.Stream()
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):
+            for _ in range(200):
+                dist.all_reduce(x, op=dist.ReduceOp.AVG)
+        torch.cuda.current_stream().wait_stream(warm)
+    else:
+        for _ in range(200):
+            dist.all_reduce(x, op=dist.ReduceOp.AVG)
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
@@ -48,7 +93,7 @@ if variant.startswith("burst"):
         if variant == "burst_unforked":
             time.sleep(0.3)
         w = dist.all_reduce(y, op=dist.ReduceOp.AVG, async_op=True)
-        if variant == "burst_forked":
+        if variant != "burst_unforked":
             time.sleep(0.3)
         w.wait()
         z = y + 1.0
