@@ -163,10 +163,13 @@ def drain_watchdog(seconds=None):
     their works -- also when no eager collective at all is issued between the recordings, and none later in ~10 000
     recordings; with it, none in ~60 processes / ~900 recordings.  So the collision needs leftover eager works in the
     watchdog's list AND a capture that holds a collective AND a poll landing inside it; the pause removes the first.
-    The precise rule inside HIP is NOT established: probes that rebuild those ingredients from the capturing thread
-    alone (200 eager all-reduces, then at once a capture with a collective held open 0.3 s) pass every time; the
-    failing runs issue their collectives from the autograd engine's thread (gradient hooks), the eager ones on a side
-    stream.  torch 2.10 no longer holds a capture back until the watchdog's list is empty (the pending-event-query
+    Made deterministic in scripts/rccl_capture_probe.py: `hooks_held` (20 eager steps whose collectives come from
+    gradient hooks, i.e. from the autograd engine's thread, then at once a capture of the same step held open 0.3 s)
+    dies 4 of 4; with 0.3 s between the eager steps and the capture it passes; the same ingredients issued from the
+    CAPTURING thread (200 eager all-reduces, on the default or a side stream, then a held-open capture with a
+    collective) pass every time.  So it takes collectives issued from another thread than the one that began the
+    thread-local capture -- which is where every backward pass's hooks run (GradBuckets here, DDP's reducer alike).
+    torch 2.10 no longer holds a capture back until the watchdog's list is empty (the pending-event-query
     counter of earlier releases is gone) and exposes no call that waits for it: everything issued so far has completed
     (the caller synchronised), the next poll removes it, and 2.5 poll periods are waited for here.  0.25 s per
     recording; DPC_WATCHDOG_DRAIN_S=0 switches it off (scripts/rccl_capture_stress.py --drain 0 shows the abort)."""

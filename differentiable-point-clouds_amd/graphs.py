@@ -15,8 +15,8 @@ What the recipe has to get right (each item was a failure on a real box or is a 
 * the watchdog's list of outstanding works is given time to empty before the capture begins
   (``distributed.drain_watchdog``): for ~100 ms after a burst of eager collectives the watchdog still holds their works,
   and a poll that lands inside a capture holding collectives can come back with hipErrorCapturedEvent -> std::terminate
-  -- the first run under RCCL in round 5 died that way, 5 of 16 stress processes without the pause, none with it (the
-  exact rule inside HIP is not pinned down, see there);
+  -- the first run under RCCL in round 5 died that way, 5 of 16 stress processes without the pause, none with it;
+  deterministic reproducer: scripts/rccl_capture_probe.py hooks_held (it takes collectives issued from the autograd thread);
 * a capture that fails half way leaves the rank's streams in capture mode and its peers waiting inside a collective:
   with more than one rank the error is raised, not swallowed;
 * nothing may keep the autograd graph of an EARLIER eager call of the same leaves alive while the step is recorded (a
