@@ -16,7 +16,8 @@ from oracle import reference_cpu as rcpu  # noqa: E402
 synth = importlib.import_module("differentiable-point-clouds_amd.synthetic")
 
 ALL_CASES = ["tiny", "tiny_probs_grad", "tiny_focal", "tiny_nokernel", "tiny_noscale",
-             "tiny_maxproj", "tiny_voxz", "tiny_matrix", "k21", "cfg1", "mid"]
+             "tiny_maxproj", "tiny_voxz", "tiny_matrix", "k21", "cfg1", "mid",
+             "k27", "voxz_onetap"]     # round 5 (tests/golden/make_round5_goldens.py): a tap count beyond 21, a one-tap z filter
 
 
 DRC_VARIANT_CASES = ["tiny_nolog", "tiny_loop", "d32_nolog"]   # drc_logsum / drc_tf_cumulative switched off
