@@ -128,7 +128,7 @@ int dpc_saved_layout(const DpcShape* shape, const DpcParams* params) {
   if (!splat_plan(*shape).ok) return 1;   // bit 0: grid_raw
   // bits 1+2: clip_mask + point_index; bit 3 (informational): grid_blur holds the xy-blurred grid, not G2;
   // bit 4 (informational): the grids are chunk-sparse for this shape right now (the rule, or dpc_set_chunk_sparse)
-  return 6 | (save_xy_mode(*shape, params->collapse_mode == DPC_COLLAPSE_DRC) ? 8 : 0) | (chunk_sparse_on(*shape) ? 16 : 0);
+  return 6 | (save_xy_mode(*shape, params->collapse_mode == DPC_COLLAPSE_DRC) ? 8 : 0) | (chunk_sparse_marks(*shape, params->collapse_mode == DPC_COLLAPSE_DRC) ? 16 : 0);
 }
 
 size_t dpc_sil_parts_per_view(const DpcShape* shape) {
@@ -554,7 +554,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
   if (yx) {
     // 2+3 fused: per-plane LDS pass (y-blur + sparse x-blur + clip bits + trilinear gather),
     // then the camera-transform VJP over the per-slot partials
-    rc = launch_gather_yx(st, S, plan, tA, pi, clip_mask, taps_x, taps_y, parts);
+    rc = launch_gather_yx(st, S, plan, tA, pi, clip_mask, taps_x, taps_y, parts, chunk_sparse_marks(S, drc));
     if (rc) return rc;
     // clouds replicated inside the kernels: per-instance point gradients go to the workspace, their sum over a
     // cloud's instances to the caller's dpc [B / R, N, 3]

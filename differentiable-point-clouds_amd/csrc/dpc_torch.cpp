@@ -164,7 +164,7 @@ struct Meta {
   int64_t collapse, dropout_keep, dropout_seed;
   double l2_weight;
   int64_t views_per_cloud, sil_C;
-  bool poison;
+  int64_t poison;    // 0 off, 1: 0xff-fill what the kernels must define, 2: ... and 0x00 over the point index / chunk marks
 };
 
 DpcParams params_of(const Meta& m, const Tensor& dropout_state) {
@@ -197,7 +197,7 @@ class ProjectFusedFn : public torch::autograd::Function<ProjectFusedFn> {
                                const optional<Tensor>& l2_target_in, const optional<Tensor>& sil_gt_in,
                                const optional<Tensor>& sil_valid_in, int64_t lib, int64_t Dz, int64_t D, double cd, double f, double eps,
                                double max_depth, bool quat, int64_t collapse, int64_t dropout_keep, int64_t dropout_seed,
-                               double l2_weight, int64_t views_per_cloud, int64_t sil_C, bool poison) {
+                               double l2_weight, int64_t views_per_cloud, int64_t sil_C, int64_t poison) {
     const Api api = api_of(lib);
     const Meta m{lib, Dz, D, cd, f, eps, max_depth, quat, collapse, dropout_keep, dropout_seed, l2_weight, views_per_cloud, sil_C, poison};
     TORCH_CHECK_VALUE(pc_in.dim() == 3 && pc_in.size(2) == 3, "point_cloud must be [B,N,3], got ", pc_in.sizes());
@@ -278,6 +278,9 @@ class ProjectFusedFn : public torch::autograd::Function<ProjectFusedFn> {
       arena.fill_(255);
       work.fill_(255);
     }
+    char* base = (char*)a256((size_t)arena.data_ptr());
+    if (poison == 2 && plan.off_pindex >= 0)     // marks nobody wrote must read "empty", not "everything marked"
+      arena.narrow(0, (int64_t)(base - (char*)arena.data_ptr()) + plan.off_pindex, plan.off_blur - plan.off_pindex).zero_();
     DpcParams params = params_of(m, dstate);
     if (l2_grad.defined()) {
       params.l2_target = (const float*)tgt.data_ptr();
@@ -291,7 +294,6 @@ class ProjectFusedFn : public torch::autograd::Function<ProjectFusedFn> {
       params.sil_C = (int32_t)sil_C;
       params.sil_S = (int32_t)sgt.size(1);
     }
-    char* base = (char*)a256((size_t)arena.data_ptr());
     dpc_stream_t st = stream_of(api, pc);
     check_rc(DPC_CALL(api.forward(st, &plan.shape, &params, (const float*)pc.data_ptr(), (const float*)pose.data_ptr(), (const float*)ptr(trans),
                          (const float*)ptr(scale), (const float*)ptr(focal), (const float*)ptr(tx), (const float*)ptr(ty),
@@ -316,7 +318,7 @@ class ProjectFusedFn : public torch::autograd::Function<ProjectFusedFn> {
     ctx->save_for_backward({pc, pose, trans, scale, focal, tx, ty, tz, tr_pc, arena, sgt, sil_w, sgt.defined() ? proj : Tensor(), dstate});
     // (two packed entries instead of twenty string-keyed ones: this runs every step)
     ctx->saved_data["i"] = std::vector<int64_t>{lib, Dz, D, quat ? 1 : 0, collapse, dropout_keep, dropout_seed, views_per_cloud, sil_C,
-                                                poison ? 1 : 0, K[0], K[1], K[2], depth.defined() ? 1 : 0, l2_grad.defined() ? 1 : 0};
+                                                poison, K[0], K[1], K[2], depth.defined() ? 1 : 0, l2_grad.defined() ? 1 : 0};
     ctx->saved_data["d"] = std::vector<double>{cd, f, eps, max_depth, l2_weight};
     if (scale.defined()) ctx->saved_data["scale_shape"] = scale_in->sizes().vec();
     if (focal.defined()) ctx->saved_data["focal_shape"] = focal_in->sizes().vec();
@@ -346,7 +348,7 @@ class ProjectFusedFn : public torch::autograd::Function<ProjectFusedFn> {
     auto& sd = ctx->saved_data;
     const std::vector<int64_t> iv = sd["i"].toIntVector();
     const std::vector<double> dv = sd["d"].toDoubleVector();
-    const Meta m{iv[0], iv[1], iv[2], dv[0], dv[1], dv[2], dv[3], iv[3] != 0, iv[4], iv[5], iv[6], dv[4], iv[7], iv[8], iv[9] != 0};
+    const Meta m{iv[0], iv[1], iv[2], dv[0], dv[1], dv[2], dv[3], iv[3] != 0, iv[4], iv[5], iv[6], dv[4], iv[7], iv[8], iv[9]};
     const Api api = api_of(m.lib);
     const int64_t R = m.views_per_cloud > 1 ? m.views_per_cloud : 1;
     const int64_t B = pc.size(0) * R, N = pc.size(1);
@@ -413,7 +415,7 @@ std::vector<optional<Tensor>> project_fused(const Tensor& pc, const Tensor& pose
                                   const optional<Tensor>& tz, const optional<Tensor>& dropout_state, const optional<Tensor>& l2_target,
                                   const optional<Tensor>& sil_gt, const optional<Tensor>& sil_valid, int64_t lib, int64_t Dz, int64_t D,
                                   double cd, double f, double eps, double max_depth, bool quat, int64_t collapse, int64_t dropout_keep,
-                                  int64_t dropout_seed, double l2_weight, int64_t views_per_cloud, int64_t sil_C, bool poison) {
+                                  int64_t dropout_seed, double l2_weight, int64_t views_per_cloud, int64_t sil_C, int64_t poison) {
   variable_list o = ProjectFusedFn::apply(pc, pose, trans, scale, focal, tx, ty, tz, dropout_state, l2_target, sil_gt, sil_valid, lib, Dz, D,
                                           cd, f, eps, max_depth, quat, collapse, dropout_keep, dropout_seed, l2_weight, views_per_cloud,
                                           sil_C, poison);

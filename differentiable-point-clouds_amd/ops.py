@@ -147,7 +147,16 @@ def uses_fused_path(lib, B, N, meta, K):
     return bool(lib.dpc_saved_layout(ctypes.byref(shape), ctypes.byref(params)) & 2)
 
 
-_POISON = bool(os.environ.get("DPC_POISON_BUFFERS"))        # read once: this sits on the per-step host path
+def _poison_mode(v):
+    """DPC_POISON_BUFFERS: unset / "0" off; "1" NaN / 0xff over every buffer the kernels must define; "2" the same, but 0x00 over
+    the fused path's point index (whose tail holds the chunk marks): a 0xff-filled mark reads "every chunk is there", which
+    hides a consumer of marks nobody wrote -- a 0x00-filled one reads "nothing is there" (round 6: the max-collapse path's
+    k_gather_yx did exactly that).  The test-suite runs its chunk-sparse and parity cases under both."""
+    v = (v or "").strip()
+    return 0 if v in ("", "0") else (2 if v == "2" else 1)
+
+
+_POISON = _poison_mode(os.environ.get("DPC_POISON_BUFFERS"))        # read once: this sits on the per-step host path
 
 
 def _poison(t):
@@ -299,6 +308,9 @@ class ProjectFused(torch.autograd.Function):
             tr_pc.fill_(float("nan"))
             arena.fill_(255)                   # 0xffffffff is a NaN, 0xff..ff a NaN double
             work.fill_(255)
+            if _POISON == 2 and plan.off_pindex >= 0:
+                o = _a256(arena.data_ptr()) - arena.data_ptr() + plan.off_pindex
+                arena[o:o + plan.off_blur - plan.off_pindex].zero_()
         if sgt is not None:
             err_parts = torch.empty(B, plan.sil_parts, dtype=torch.float32, device=dev)
             sil = (sgt.data_ptr(), err_parts.data_ptr(), None, None, None, int(meta.sil_C), int(sgt.shape[1]))

@@ -1,0 +1,98 @@
+"""Host-side model of the wave-uniform sparse z-walk (round 6): how many plane steps of k_zfwd / k_zbwd are dead
+under different skip granularities, on the bench's own clouds (numpy only, no GPU).
+  python scripts/dev_r06/sparse_walk_model.py [cfg ...]"""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+import dpc_amd
+from oracle import dpc_oracle_np as onp
+
+
+def marks_for(cfg_id, B=None, K=None, N=None, D=None):
+    c = dict(dpc_amd.synthetic.CONFIGS.get(cfg_id, {}))
+    if cfg_id == 3:
+        c = dict(B=32, N=8000, D=64, K=21, sigma=3.0)
+    if B: c["B"] = B
+    if K: c["K"] = K
+    inp = dpc_amd.synthetic.make_inputs(c["B"], c["N"], dpc_amd.synthetic.SEED0 + cfg_id)
+    tr = onp.transform_fwd(inp["pc"].astype(np.float64), inp["pose"].astype(np.float64))
+    tr = (tr[0] if isinstance(tr, tuple) else tr).astype(np.float32)
+    D = c["D"]; H = c["K"] // 2
+    valid = np.all((tr >= -0.5) & (tr <= 0.5), axis=-1)
+    cell = lambda i: np.floor((tr[..., i] + np.float32(0.5)) * np.float32(D - 1)).astype(np.int64).clip(0, D - 1)
+    iz, iy, ix = cell(0), cell(1), cell(2)
+    out = []
+    for b in range(tr.shape[0]):
+        v = valid[b]
+        z0, y0, x0 = iz[b][v], iy[b][v], ix[b][v]
+        mark = np.zeros((D + 1, D, D // 32), dtype=bool)
+        c_lo, c_hi = np.maximum(x0 - H, 0) >> 5, np.minimum(x0 + 1 + H, D - 1) >> 5
+        for dy in range(-H, H + 2):
+            y = y0 + dy
+            ok = (y >= 0) & (y < D)
+            for dz in (0, 1):
+                for cc in (c_lo, c_hi):
+                    mark[z0[ok] + dz, y[ok], cc[ok]] = True
+        out.append(mark[:D])
+    return c, np.stack(out)      # [B, Dz, D, D/32]
+
+
+def wave_masks(mark, D, rows=1):
+    B, Dz = mark.shape[:2]
+    if rows > 1:      # a wave = (4 / rows) chunks x `rows` rows
+        cpw = 4 // rows
+        m = mark.reshape(B, Dz, D // rows, rows, (D // 32) // cpw, cpw).any(-1).any(3)
+        m = m.reshape(B, Dz, -1)
+    elif D >= 128:      # a wave = 128 rays = 4 chunks of one row
+        m = mark.reshape(B, Dz, D, D // 128, 4).any(-1)          # [B,Dz,D,waves/row]
+        m = m.reshape(B, Dz, -1)
+    else:             # a wave = 128 / D rows
+        r = 128 // D
+        m = mark.any(-1).reshape(B, Dz, D // r, r).any(-1)
+    return np.moveaxis(m, 1, -1).reshape(-1, Dz)     # [waves, Dz]
+
+
+def dead_steps(wm, lookback, Dz, T, lag=0):
+    """step t (0..T-1) pushes plane t; dead iff no marked plane in [t - lookback, t]"""
+    W = wm.shape[0]
+    pad = np.zeros((W, T + lookback), dtype=bool)
+    pad[:, lookback:lookback + Dz] = wm
+    cs = np.concatenate([np.zeros((W, 1), int), np.cumsum(pad, 1)], 1)
+    t = np.arange(T)
+    cnt = cs[:, t + lookback + 1] - cs[:, t]
+    return cnt == 0     # [W, T]
+
+
+def report(cfg_id, **kw):
+    c, mark = marks_for(cfg_id, **kw)
+    for rows in ((1, 2, 4) if c["D"] >= 128 else (1,)):
+        report1(cfg_id, c, mark, rows)
+
+
+def report1(cfg_id, c, mark, rows):
+    D, K = c["D"], c["K"]; Dz = D; h = K // 2
+    wm = wave_masks(mark, D, rows)
+    print("rows/wave %d:" % rows)
+    print("cfg%d D=%d K=%d: chunks marked %.3f, wave-planes marked %.3f, waves all-empty %.3f" %
+          (cfg_id, D, K, mark.mean(), wm.mean(), (~wm.any(1)).mean()))
+    G = K if K >= 4 else 2 * K
+    for name, T, look in (("zfwd", Dz + h, K), ("zbwd", Dz + 2 * h, 2 * K - 1)):
+        d = dead_steps(wm, look, Dz, T)
+        line = "  %s: plane-level dead %.3f" % (name, d.mean())
+        for S in (2, 3, 4, 6, G):
+            nb = (T + S - 1) // S
+            dd = np.ones((d.shape[0], nb * S), bool); dd[:, :T] = d
+            blk = dd.reshape(d.shape[0], nb, S).all(-1)
+            line += " | S=%d: %.3f" % (S, (blk.sum() * S) / (d.shape[0] * T))
+        print(line)
+    # staged rules for zbwd: (A) input plane nonzero -> fwd FMAs; (B) G2[t-h] nonzero -> full DRC + adjoint FMAs; (C) output nonzero / store
+    T = Dz + 2 * h
+    inp_dead = dead_steps(wm, 0, Dz, T)
+    g2_dead = dead_steps(wm, 2 * h, Dz, T)
+    print("  zbwd staged: input-plane dead %.3f, G2 dead %.3f (both K=%d)" % (inp_dead.mean(), g2_dead.mean(), K))
+
+
+if __name__ == "__main__":
+    for a in (sys.argv[1:] or ["2", "5", "3"]):
+        report(int(a), **({"B": 4} if int(a) == 5 else {}))
+    report(3, K=9)

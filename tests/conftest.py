@@ -72,3 +72,13 @@ def emu(emu_library):
     prev = dpc_amd._capi.set_library(emu_library)
     yield emu_library
     dpc_amd._capi.set_library(prev)
+
+
+@pytest.fixture(params=[1, 2], ids=["poison_ff", "poison_marks_00"])
+def poison_mode(request, monkeypatch):
+    """DPC_POISON_BUFFERS modes 1 and 2 (ops._poison_mode): 0xff over everything the kernels must define -- and, mode 2, 0x00
+    over the point index whose tail holds the chunk marks.  A 0xff mark reads 'this chunk is there', so a consumer of marks
+    nobody wrote passes under mode 1 and drops chunks under mode 2."""
+    import dpc_amd
+    monkeypatch.setattr(dpc_amd.ops, "_POISON", request.param)
+    return request.param

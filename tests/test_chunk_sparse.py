@@ -96,7 +96,7 @@ def test_emu_sparse_form_writes_fewer_chunks_and_the_same_images(lib, D, K, N):
 
 
 @pytest.mark.parametrize("case", [(2, 300, 32, 5, 0.9), (2, 500, 64, 9, 1.4), (1, 400, 64, 21, 3.0)])
-def test_emu_both_forms_agree_bit_for_bit(lib, case):
+def test_emu_both_forms_agree_bit_for_bit(lib, poison_mode, case):
     both_forms_agree_bit_for_bit(lib, "cpu", *case)
 
 
@@ -107,7 +107,7 @@ def test_emu_both_forms_agree_on_a_256_wide_grid(lib):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
-def test_emu_reference_conventions_hold_in_both_forms(lib, mode):
+def test_emu_reference_conventions_hold_in_both_forms(lib, poison_mode, mode):
     """knife edges (corner cells of weight exactly 0 still carry a gradient: the chunk flags are geometry, not values) with the
     layout forced either way; forced sparse also dropout, the fused loss, a dense-gather plane (the dense form of those is what
     the other emulation tests run wherever the rule says so)"""
@@ -168,5 +168,5 @@ def test_gpu_sparse_form_writes_fewer_chunks_and_the_same_images(gpu_lib, D, K, 
                                   (40, 8000, 64, 21, 3.0),         # ... and early (21 taps: the rule keeps the dense form)
                                   (4, 16000, 256, 11, 2.0),        # configs[4]'s grid
                                   (8, 560, 64, 5, 0.9)])
-def test_gpu_both_forms_agree_bit_for_bit(gpu_lib, case):
+def test_gpu_both_forms_agree_bit_for_bit(gpu_lib, poison_mode, case):
     both_forms_agree_bit_for_bit(gpu_lib, "cuda", *case)
