@@ -373,34 +373,49 @@ def source_sha256():
     return h.hexdigest()
 
 
-def pmc_traffic(lib, args, case):
+def pmc_traffic(lib, args, case, fname="traffic.json", script="scripts/gpu_round6.sh (section pmc)"):
     """PMC-measured bytes per launch from profiles/traffic.json -- only if they were taken on THIS build of the library
-    (the file carries the sha256 of the libdpc_hip.so it was measured on; scripts/gpu_round5.sh writes both) and on
-    this workload.  Returns (entry | {}, source | None, note | None)."""
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    (the file carries the sha256 of the libdpc_hip.so it was measured on; scripts/gpu_round6.sh writes both) and on
+    this workload.  Returns (entry | {}, source | None, note | None).  fname="issue.json": the SQ-counter figures of
+    scripts/summarize_sq.py under the same rule."""
+    tpath = os.path.join(ROOT, "profiles", fname)
     if not os.path.exists(tpath):
-        return {}, None, "no profiles/traffic.json"
+        return {}, None, "no profiles/" + fname
     try:
         doc = json.load(open(tpath))
     except (ValueError, OSError) as e:
-        return {}, None, "profiles/traffic.json unreadable (%s)" % e
+        return {}, None, "profiles/%s unreadable (%s)" % (fname, e)
     default_sigma = {1: 1.0, 2: 1.6, 3: 3.0, 5: 2.0}[args.config]
     key = "config%d" % args.config + ("" if args.sigma in (None, default_sigma) else "_sigma%g" % args.sigma)
     if args.k is not None or args.vox is not None or args.num_points is not None or args.points != "shell":
         return {}, None, "no PMC passes for this workload variant"
     ent = doc.get(key)
     if ent is None:
-        return {}, None, "profiles/traffic.json has no entry %r" % key
+        return {}, None, "profiles/%s has no entry %r" % (fname, key)
     # Only the hash of the BINARY counts (round 4 accepted the kernel sources' hash as well, and that stamp had been edited by
-    # hand after source changes): the file is written -- numbers and stamp together -- by scripts/gpu_round5.sh on the GPU box,
+    # hand after source changes): the file is written -- numbers and stamp together -- by the GPU session script on the GPU box,
     # from the library that travelled there, which is the library the driver's bench run loads.
     if doc.get("lib_sha256") != library_sha256(lib):
-        return {}, None, ("profiles/traffic.json was measured on another build of libdpc_hip.so (library sha256 %s..., this one "
-                          "%s...): re-run scripts/gpu_round5.sh (section pmc) and copy its traffic.json unedited"
-                          % (str(doc.get("lib_sha256"))[:12], library_sha256(lib)[:12]))
+        return {}, None, ("profiles/%s was measured on another build of libdpc_hip.so (library sha256 %s..., this one "
+                          "%s...): re-run %s and copy the file unedited"
+                          % (fname, str(doc.get("lib_sha256"))[:12], library_sha256(lib)[:12], script))
     if case["B"] != ent.get("B") or case["N"] != ent.get("N", case["N"]):
-        return {}, None, "profiles/traffic.json entry %r is for another batch / point count" % key
-    return ent, "profiles/traffic.json[%s] (rocprofv3 --pmc passes on this build, see profiles/README.md)" % key, None
+        return {}, None, "profiles/%s entry %r is for another batch / point count" % (fname, key)
+    return ent, "profiles/%s[%s] (rocprofv3 --pmc passes on this build, see profiles/README.md)" % (fname, key), None
+
+
+def binding_bound(hbm_frac, issue):
+    """Which resource binds the dominant kernel: the largest of (a) the HBM fraction -- PMC-measured bytes where they exist for
+    this build, else the bytes the kernel must move -- over the 8 TB/s peak, (b) `valu_busy`, the share of the chip's vector
+    issue slots the kernel fills (SQ counters), provided one of them reaches 0.5; below that nothing is saturated and the
+    kernel waits -- on memory / LDS latency it cannot cover at its occupancy (wait_any_frac) or on its own dependent chains
+    (wait_inst_frac): "latency".  Without SQ counters for this build the decision cannot be made: "hbm (unverified)"."""
+    if not issue:
+        return "hbm (unverified: no SQ counters for this build)", None
+    cand = {"hbm": hbm_frac, "valu-issue": issue["valu_busy"]}
+    top = max(cand, key=cand.get)
+    why = {"hbm_frac": hbm_frac, "valu_busy": issue["valu_busy"], "rule": "max(hbm_frac, valu_busy) if it reaches 0.5, else latency"}
+    return (top if cand[top] >= 0.5 else "latency"), why
 
 
 def self_launch(ngpus, argv):
@@ -649,6 +664,9 @@ def main():
         ent, tsrc, tnote = pmc_traffic(lib, args, case) if not train else ({}, None, "training step: projector traffic not taken")
         traffic = ent.get(dom)
         step_traffic = ent.get("_step_total")
+        ient, isrc, inote = (pmc_traffic(lib, args, case, "issue.json", "scripts/gpu_round6.sh (section sq)") if not train
+                             else ({}, None, "training step: SQ counters not taken"))
+        issue = ient.get(dom) if isinstance(ient.get(dom), dict) else None
         proj_ms = sum(per_step.values()) if train else ms_step     # config 3: the projector's share of the step
         ceil = hbm_ceilings(lib, device)
         ach = (rd + wr) / (dom_ms * 1e-3) / 1e9
@@ -658,8 +676,14 @@ def main():
         V = 4 * case["D"] ** 3
         model_step = dpc_amd.synthetic.algorithmic_bytes_per_view(case["N"], case["D"], case["D"]) * case["B"]
         model_kernel = {"zfwd": 1, "zbwd": 2, "splat_xy": 1, "gather_yx": 1}.get(dom)
-        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        hbm_frac = (traffic if traffic is not None else rd + wr) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        bound, bound_why = binding_bound(hbm_frac, issue)
+        roof = {"bound": bound, "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
+                # the instruction-issue side of the same kernel (SQ counters of THIS build): `frac` says how far the kernel is from
+                # the HBM roof, issue.valu_busy how far from the vector-issue roof -- `bound` names the larger (binding_bound)
+                "issue": issue, "issue_source": isrc, **({"issue_note": inote} if inote else {}),
+                **({"bound_basis": bound_why} if bound_why else {}),
                 "traffic": traffic, "traffic_source": tsrc, **({"traffic_note": tnote} if tnote else {}),
                 "measured_achieved": None if traffic is None else traffic / (dom_ms * 1e-3) / 1e9,
                 "kernel_ms": dom_ms, "kernel_launches_per_step": launches_per_step,

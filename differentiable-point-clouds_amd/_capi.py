@@ -81,6 +81,7 @@ SIGNATURES = {
     "dpc_student_loss": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, ctypes.c_float, _P, _P]),
     "dpc_point_index_ints": (ctypes.c_size_t, [_SP]),
     "dpc_set_chunk_sparse": (ctypes.c_int, [ctypes.c_int]),
+    "dpc_set_sparse_walk": (ctypes.c_int, [ctypes.c_int]),
     "dpc_sil_parts_per_view": (ctypes.c_size_t, [_SP]),
     "dpc_silhouette_select": (ctypes.c_int, [_P] + [ctypes.c_int] * 3 + [_P] * 6),
     "dpc_nn_distance": (ctypes.c_int, [_P] + [ctypes.c_int] * 3 + [_P] * 5),

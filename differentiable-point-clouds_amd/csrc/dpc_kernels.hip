@@ -116,6 +116,12 @@ int dpc_compiled_taps(int K) {
 
 int dpc_set_chunk_sparse(int mode) { return chunk_sparse_mode().exchange(mode < 0 ? -1 : (mode ? 1 : 0)); }
 
+int dpc_set_sparse_walk(int on) { return sparse_walk_mode().exchange(on ? 1 : 0); }
+#ifdef DPC_EMU
+// (CPU test tier only) dead groups the emulated wavefronts of the z kernels took since the last call
+long long dpc_emu_dead_groups_take(void) { return dpc_emu_dead_groups().exchange(0); }
+#endif
+
 int dpc_profile_enable(int on) {
   dpcprof::clear();
   std::lock_guard<std::mutex> lk(dpcprof::g_mu);
@@ -524,7 +530,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
     if (e != hipSuccess) return (int)e;
   }
   float* ds_acc = scale ? accum : nullptr;
-  const int nzb = zbwd_blocks(S);
+  int nzb = zbwd_blocks(S);      // (the fused z kernel reports the work-groups per view it really used)
   // 1. collapse VJP (+ z-FIR adjoint) -> tA
   const bool yx = use_cmask;   // consumer of tA is k_gather_yx (reads occupied planes only)
   PointIndex pi = {nullptr, nullptr, nullptr, nullptr};
@@ -533,7 +539,7 @@ int dpc_project_backward(dpc_stream_t stream, const DpcShape* shape, const DpcPa
     const unsigned* live = yx ? pi.live : nullptr;
     // fused forward (plan.ok): grid_blur holds the xy-blurred grid, see dpc_project_forward
     rc = launch_zbwd(st, S, P, grid_blur, taps_z, S.Kz, scale, ray_sums, dproj, dproj_depth, nullptr, tA,
-                     ds_acc, 1, live, scale ? dsparts : nullptr, accum, pi.live, use_cmask && save_xy_mode(S, drc));
+                     ds_acc, 1, live, scale ? dsparts : nullptr, accum, pi.live, use_cmask && save_xy_mode(S, drc), &nzb);
     if (rc) return rc;
   } else {
     float* first = (S.Kz > 0) ? tB : tA;

@@ -176,6 +176,13 @@ size_t dpc_point_index_ints(const DpcShape* shape);
  * (forward and backward of one step must see the same mode), -1 restores the rule; returns the previous mode.
  * For A/B measurements and for tests that compare the two forms bit for bit. */
 int dpc_set_chunk_sparse(int mode);
+/* The sparse z walk (new, round 6; no reference counterpart -- the reference's tf.cumsum / conv3d over the depth axis touch every
+ * plane, dpc/util/drc.py:47-123, dpc/util/point_cloud.py:139-145): a wavefront of the fused collapse kernels skips, behind one
+ * scalar branch per group of plane steps, the groups in which none of its rays has anything within the blur's reach, advancing
+ * only the ray state -- in the dense walk's order with the dense walk's operations, so both walks agree bit for bit.
+ * on != 0 (the default) enables it, 0 makes every wavefront walk every plane for the calls that follow; returns the previous
+ * setting.  For A/B measurements and for the tests that compare the two walks. */
+int dpc_set_sparse_walk(int on);
 
 /* Bytes of scratch `dpc_project_forward` (direction 0) / `dpc_project_backward`
  * (direction 1) need.  256-byte aligned device memory. */

@@ -19,12 +19,20 @@ if os.environ.get("AB_SHAPE"):      # e.g. AB_SHAPE=320,8000,64,21,3.0  (B,N,D,K
     cfg_id = 9
 B = os.environ.get("AB_BATCH")
 case = bench.build_case(cfg_id, int(B) if B else None, torch.device("cuda"))
-libs = [(os.path.basename(p), dpc_amd._capi.DpcLibrary(os.path.abspath(p))) for p in sys.argv[1:]]
+# lib.so[@walk0][@cs0]: the same build with the sparse z walk / the chunk-sparse layout switched off (round 6)
+libs, opts = [], {}
+for spec in sys.argv[1:]:
+    path, *flags = spec.split("@")
+    name = os.path.basename(path) + "".join("@" + f for f in flags)
+    libs.append((name, dpc_amd._capi.DpcLibrary(os.path.abspath(path))))
+    opts[name] = flags
 rounds, steps = 3, 20
 res = {n: {"ms": [], "k": {}} for n, _ in libs}
 for r in range(rounds):
     for name, lib in libs:
         dpc_amd._capi.set_library(lib)
+        lib.dpc_set_sparse_walk(0 if "walk0" in opts[name] else 1)
+        lib.dpc_set_chunk_sparse(0 if "cs0" in opts[name] else -1)
         for _ in range(5):
             bench.step(case)
         torch.cuda.synchronize()

@@ -96,3 +96,82 @@ if __name__ == "__main__":
     for a in (sys.argv[1:] or ["2", "5", "3"]):
         report(int(a), **({"B": 4} if int(a) == 5 else {}))
     report(3, K=9)
+
+
+def balance_report(cfg_id, B=None):
+    """per-SIMD work under the balanced 1024-thread work-groups (zray_tile_balanced), cost of a dead group = 0.13 of a dense one"""
+    c, mark = marks_for(cfg_id, B=B)
+    D, K = c["D"], c["K"]; Dz = D; h = K // 2; G = K
+    NB = mark.shape[0]
+    NC, RG = D // 32, D // 4
+    tile_any = mark.reshape(NB, Dz, RG, 4, NC).any(3)            # [B, Dz, RG, NC]
+    for name, T, look in (("zfwd", Dz + h, K), ("zbwd", Dz + 2 * h, 2 * K - 1)):
+        ng = (T + G - 1) // G
+        cost = np.zeros((NB, RG, NC))
+        for g in range(ng):
+            lo, hi = max(g * G - look, 0), min(g * G + G - 1, Dz - 1)
+            dead = ~tile_any[:, lo:hi + 1].any(1) if hi >= lo else np.ones((NB, RG, NC), bool)
+            cost += np.where(dead, 0.13, 1.0)
+        cost /= ng
+        mul2 = [0, 2, 3, 1]
+        q = max(NC // 4, 1)
+        nwg = (RG // 4) * q if NC >= 4 else RG // 8
+        res = {}
+        for hyp in ("w%4", "w/4"):
+            simd = np.zeros((NB, nwg, 4))
+            for g in range(nwg):
+                for w in range(16):
+                    s, j = w & 3, w >> 2
+                    a, b = s ^ j, mul2[s] ^ j
+                    if NC >= 4:
+                        rg, cc = g // q + a * (RG // 4), g % q + q * b
+                    else:
+                        rg, cc = g + a * (RG // 4) + (b >> 1) * (RG // 8), b & 1
+                    simd[:, g, s if hyp == "w%4" else j] += cost[:, rg, cc]
+            res[hyp] = simd / 4
+        # plain tile order, 4-wave work-groups: wave v -> chunk v % NC of row group v / NC; no control over which 4 WGs share a SIMD: report the per-wave spread
+        print("cfg%d %s: mean cost %.3f | balanced WGs: per-SIMD mean %.3f max %.3f (w%%4), max %.3f (w/4); per-CU max %.3f | per-wave max %.3f" % (
+            cfg_id, name, cost.mean(), res["w%4"].mean(), res["w%4"].max(), res["w/4"].max(), res["w%4"].mean(-1).max(), cost.max()))
+
+
+if __name__ == "__main__" and os.environ.get("BALANCE"):
+    balance_report(2)
+    balance_report(5, B=4)
+
+
+def balance_mixed(cfg_id, B=None):
+    c, mark = marks_for(cfg_id, B=B)
+    D, K = c["D"], c["K"]; Dz = D; h = K // 2; G = K
+    NB = mark.shape[0]
+    NC, RG = D // 32, D // 4
+    tile_any = mark.reshape(NB, Dz, RG, 4, NC).any(3)
+    for name, T, look in (("zfwd", Dz + h, K), ("zbwd", Dz + 2 * h, 2 * K - 1)):
+        ng = (T + G - 1) // G
+        cost = np.zeros((NB, RG, NC))
+        for g in range(ng):
+            lo, hi = max(g * G - look, 0), min(g * G + G - 1, Dz - 1)
+            dead = ~tile_any[:, lo:hi + 1].any(1) if hi >= lo else np.ones((NB, RG, NC), bool)
+            cost += np.where(dead, 0.13, 1.0)
+        cost /= ng
+        mul2 = [0, 2, 3, 1]
+        q = max(NC // 4, 1)
+        nwg = (RG // 4) * q if NC >= 4 else RG // 8
+        for vs in (0, NB // 4, 1):        # view stride between the 4 waves of a SIMD
+            simd = np.zeros((NB, nwg, 4))
+            for by in range(NB):
+                for g in range(nwg):
+                    for w in range(16):
+                        s, j = w & 3, w >> 2
+                        a, b = s ^ j, mul2[s] ^ j
+                        if NC >= 4:
+                            rg, cc = g // q + a * (RG // 4), g % q + q * b
+                        else:
+                            rg, cc = g + a * (RG // 4) + (b >> 1) * (RG // 8), b & 1
+                        simd[by, g, s] += cost[(by + j * vs) % NB, rg, cc]
+            print("cfg%d %s view stride %d: per-SIMD mean %.3f max %.3f  p99 %.3f | per-CU max %.3f" % (cfg_id, name, vs, simd.mean() / 4, simd.max() / 4,
+                  np.percentile(simd, 99) / 4, simd.mean(-1).max() / 4))
+
+
+if __name__ == "__main__" and os.environ.get("BALANCE2"):
+    balance_mixed(2)
+    balance_mixed(5, B=8)

@@ -7,7 +7,7 @@ import sys
 from collections import Counter
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-txt = open(os.path.join(ROOT, "differentiable-point-clouds_amd", "csrc", "dpc_kernels.gfx950.s")).read()
+txt = open(os.path.join(ROOT, "differentiable-point-clouds_amd", "csrc", os.environ.get("DPC_ASM", "dpc_kernels.gfx950.s"))).read()
 flt = sys.argv[1:]
 print("%-58s %5s %5s %4s %7s %6s | %5s %5s %5s %4s %5s %8s" % ("kernel", "VGPR", "SGPR", "occ", "scratch", "LDS", "valu", "v_pk", "salu", "ds", "vmem", "readlane"))
 for m in re.finditer(r"^(_Z\w+):.*?\n(.*?\.end_amdhsa_kernel.*?; Occupancy: \d+)", txt, re.S | re.M):

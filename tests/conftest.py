@@ -63,7 +63,13 @@ def emu_library():
     import dpc_amd
     # (kernel experiments: DPC_EMU_LIB names a variant built with `make -C tests/hipemu OUT=... EXTRA=-D...`)
     name = os.environ.get("DPC_EMU_LIB", "libdpc_emu.so")
-    return dpc_amd._capi.DpcLibrary(os.path.join(emu_dir, name), host_memory=True)
+    lib = dpc_amd._capi.DpcLibrary(os.path.join(emu_dir, name), host_memory=True)
+    # emulation-only hook: dead groups taken by the z kernels' wavefronts since the last call (the sparse walk's tests)
+    import ctypes
+    lib.dpc_emu_dead_groups_take = lib._dll.dpc_emu_dead_groups_take
+    lib.dpc_emu_dead_groups_take.restype = ctypes.c_longlong
+    lib.dpc_emu_dead_groups_take.argtypes = []
+    return lib
 
 
 @pytest.fixture()
