@@ -212,6 +212,7 @@ Pool& pool() {
 }
 }  // namespace
 
+unsigned concurrency() { return pool().nworkers; }
 void sync() { t_runner->sync_block(); }
 void wave_sync() { t_runner->sync_wave(); }
 

@@ -16,6 +16,7 @@
 // blocks, as on the GPU.  Wave shuffles go through a per-block exchange buffer and rendezvous per WAVE: they may sit in
 // wave-uniform (not necessarily block-uniform) control flow.  Wavefront width is 64, as on gfx950.
 #pragma once
+#include <sched.h>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -60,6 +61,7 @@ struct Block {
   unsigned int* xchg;      // per-thread 32-bit exchange words for shuffles
   int vote;
 };
+unsigned concurrency();                // OS threads of the block pool = work-groups that run concurrently (block i on thread i % n)
 extern thread_local Ctx* t_ctxp;       // the fiber that is running on this OS thread
 extern thread_local Block* t_block;
 inline Ctx& cur() { return *t_ctxp; }
@@ -214,6 +216,7 @@ static inline void dpc_pk_mul_tap(dpc_v2f& acc, dpc_v2f pair, dpc_v2f v) {
 static inline void dpc_consume(float) {}
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only used on wave-uniform values
+static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }          // (a spin on a counter another work-group's OS thread advances)
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
   memset(p, v, n);
   return hipSuccess;

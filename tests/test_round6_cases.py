@@ -194,3 +194,84 @@ def test_emu_sparse_walk_against_the_numpy_oracle(emu):
 def test_gpu_both_walks_agree_bit_for_bit(gpu_lib, poison_mode, case):
     B, N, D, K, sigma, Dz, depth, cs = case
     both_walks_agree_bit_for_bit(gpu_lib, "cuda", B, N, D, K, sigma, Dz=Dz, with_depth=depth, cs=cs)
+
+
+# ---- the depth sort's three forms (one work-group per view / two launches / several work-groups per view in one launch) ----------
+_SORT_SCRIPT = r'''
+import ctypes, hashlib, json, os, sys
+import numpy as np
+import torch
+root = sys.argv[1]; dev = sys.argv[2]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import dpc_amd
+if dev == "cpu":
+    dpc_amd._capi.set_library(dpc_amd._capi.DpcLibrary(os.path.join(root, "tests", "hipemu", "libdpc_emu.so"), host_memory=True))
+lib = dpc_amd.get_library()
+B, N, D, K = 3, 2500, 32, 5
+inp = dpc_amd.synthetic.make_inputs(B, N, 31)
+pc, pose = torch.tensor(inp["pc"], device=dev), torch.tensor(inp["pose"], device=dev)
+cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K)
+taps = [k.reshape(-1).contiguous() for k in dpc_amd.smoothing_kernel(cfg, 0.9, device=dev)]
+S = dpc_amd._capi.DpcShape(B, N, D, D, K, K, K)
+P = dpc_amd._capi.DpcParams(2.0, 1.875, 1e-5, 10.0, 1, 0, 0, 0, 0)
+z = lambda *s, **kw: torch.zeros(*s, device=dev, **kw)
+tr_pc, cmask = z(B, N, 3), z(B, N, 4, dtype=torch.uint8)
+pindex = torch.full((lib.dpc_point_index_ints(ctypes.byref(S)),), -1, dtype=torch.int32, device=dev)
+grid = z(B, D, D, D); sums, proj, depth = z(B, D, D, 2, dtype=torch.float64), z(B, D, D), z(B, D, D)
+nws = lib.dpc_workspace_bytes(ctypes.byref(S), 0)
+ws = torch.full((nws + 256,), 255, dtype=torch.uint8, device=dev)
+p = lambda x: ctypes.c_void_p(x.data_ptr())
+stream = None if dev == "cpu" else ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+rc = lib.dpc_project_forward(stream, ctypes.byref(S), ctypes.byref(P), p(pc), p(pose), None, None, None, p(taps[0]), p(taps[1]), p(taps[2]),
+                             p(tr_pc), None, p(cmask), p(pindex), p(grid), p(sums), p(proj), p(depth), ctypes.c_void_p((ws.data_ptr() + 255) & ~255), nws)
+lib.check(rc, "dpc_project_forward")
+if dev != "cpu":
+    torch.cuda.synchronize()
+pi = pindex.cpu().numpy(); tr = tr_pc.cpu().numpy()
+srec = pi[:4 * B * N].view(np.float32).reshape(B, N, 4); slot_of = pi[4 * B * N:5 * B * N].reshape(B, N)
+zstart = pi[5 * B * N:5 * B * N + B * (D + 2)].reshape(B, D + 2)
+ok = True
+for b in range(B):
+    n = srec[b, :, 3].view(np.int32)
+    ok &= bool(np.array_equal(np.sort(n), np.arange(N)))                     # every point exactly once
+    ok &= bool(np.array_equal(slot_of[b][n], np.arange(N)))                   # slot_of is the inverse map
+    ok &= bool(np.array_equal(srec[b, :, :3], tr[b][n]))                      # the records carry the transformed points
+    valid = np.all((tr[b] >= -0.5) & (tr[b] <= 0.5), axis=-1)
+    cell = np.floor((tr[b][:, 0] + np.float32(0.5)) * np.float32(D - 1)).astype(np.int64).clip(0, D - 1)
+    bucket = np.where(valid, cell, D)
+    ok &= bool(zstart[b, 0] == 0 and zstart[b, D + 1] == N and np.all(np.diff(zstart[b]) >= 0))
+    ok &= bool(np.all((slot_of[b] >= zstart[b][bucket]) & (slot_of[b] < zstart[b][bucket + 1])))   # every point inside its bucket
+print(json.dumps({"ok": ok, "proj": hashlib.sha256(proj.cpu().numpy().tobytes()).hexdigest(),
+                  "depth": hashlib.sha256(depth.cpu().numpy().tobytes()).hexdigest(), "zstart": zstart.tolist()}))
+'''
+
+
+def _sort_forms(dev):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for form in ("0", "1", "2"):
+        env = dict(os.environ, DPC_ZSORT_SPLIT=form, DPC_TEST_HOOKS="1")
+        env.pop("DPC_POISON_BUFFERS", None)
+        out = subprocess.run([sys.executable, "-c", _SORT_SCRIPT, root, dev], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[form] = json.loads(out.stdout.strip().splitlines()[-1])
+        assert res[form]["ok"], "form %s: the sorted records are not a bucket sort of the view's points" % form
+    # the same buckets, and -- the splat adds integers -- bitwise the same images whatever the order inside a bucket
+    assert res["0"]["zstart"] == res["1"]["zstart"] == res["2"]["zstart"]
+    assert res["0"]["proj"] == res["1"]["proj"] == res["2"]["proj"] and res["0"]["depth"] == res["2"]["depth"]
+
+
+def test_emu_depth_sort_three_forms_agree(emu):
+    """DPC_ZSORT_SPLIT=0 / 1 / 2: k_zsort, k_zhist + k_zscatter, k_zsort_multi (round 6: G work-groups per view meeting through
+    a zeroed row of counters, one launch) on a case with three work-groups per view (N = 2500), each in its own process
+    (the switch is read once): a valid bucket sort each, identical bucket starts, bitwise identical images."""
+    _sort_forms("cpu")
+
+
+@pytest.mark.gpu
+def test_gpu_depth_sort_three_forms_agree(gpu_lib):
+    _sort_forms("cuda")
