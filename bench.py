@@ -409,9 +409,10 @@ def binding_bound(hbm_frac, issue):
     this build, else the bytes the kernel must move -- over the 8 TB/s peak, (b) `valu_busy`, the share of the chip's vector
     issue slots the kernel fills (SQ counters), provided one of them reaches 0.5; below that nothing is saturated and the
     kernel waits -- on memory / LDS latency it cannot cover at its occupancy (wait_any_frac) or on its own dependent chains
-    (wait_inst_frac): "latency".  Without SQ counters for this build the decision cannot be made: "hbm (unverified)"."""
+    (wait_inst_frac): "latency".  Without SQ counters for this build the decision cannot be made: "hbm" stays (the survey's classification) with a note saying so."""
     if not issue:
-        return "hbm (unverified: no SQ counters for this build)", None
+        return "hbm", {"note": "unverified: no SQ counters (profiles/issue.json) for this build of the library -- 'hbm' is the "
+                               "survey's classification of the path (SURVEY.md 8(d)), not a measurement"}
     cand = {"hbm": hbm_frac, "valu-issue": issue["valu_busy"]}
     top = max(cand, key=cand.get)
     why = {"hbm_frac": hbm_frac, "valu_busy": issue["valu_busy"], "rule": "max(hbm_frac, valu_busy) if it reaches 0.5, else latency"}

@@ -175,3 +175,25 @@ def balance_mixed(cfg_id, B=None):
 if __name__ == "__main__" and os.environ.get("BALANCE2"):
     balance_mixed(2)
     balance_mixed(5, B=8)
+
+
+def yblur_blocks(cfg_id, B=None):
+    """k_splat_xy's y-blur by column block: of the (plane, strip) tiles that hold anything, which share of their column blocks
+    (32 columns at VY = 2, 64 at VY = 4) holds a marked chunk in any of the strip's rows"""
+    c, mark = marks_for(cfg_id, B=B)
+    D = c["D"]
+    SH = {64: 64, 128: 64, 256: 32}[D]
+    CW = 32 if D <= 128 else 64
+    NB = mark.shape[0]
+    m = mark.reshape(NB, D, D // SH, SH, D // 32)              # [B, Dz, strips, rows, chunks]
+    blk = m.any(3)                                             # [B, Dz, strips, chunks]
+    if CW == 64:
+        blk = blk.reshape(NB, D, D // SH, D // 64, 2).any(-1)
+    live = blk.any(-1)
+    print("cfg%d: live tiles %.3f of all; marked column blocks among live tiles %.3f; rows of a live tile with any mark %.3f" % (
+        cfg_id, live.mean(), blk[live].mean(), m.any(-1)[live].mean()))
+
+
+if __name__ == "__main__" and os.environ.get("YBLUR"):
+    yblur_blocks(2)
+    yblur_blocks(5, B=4)

@@ -112,7 +112,7 @@ def sha_sources():          # the same digest as bench.py source_sha256()
 
 if "--traffic" in sys.argv:
     doc = {"_doc": "HBM bytes per launch (median over launches) from rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate "
-                   "passes (scripts/gpu_round5.sh -> scripts/summarize_profiles4.py), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: the "
+                   "passes (scripts/gpu_round6.sh -> scripts/summarize_profiles4.py), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: the "
                    "factor 2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md (HBM), re-calibrated in the same "
                    "session with k_copy<1|2|4> on 512 MiB buffers.  lib_sha256 / src_sha256: the build of libdpc_hip.so (and "
                    "its sources, for information) the counters were taken on -- bench.py quotes these bytes only for the build with that lib_sha256; written by the script only, never edited.",

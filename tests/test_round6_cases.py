@@ -275,3 +275,35 @@ def test_emu_depth_sort_three_forms_agree(emu):
 @pytest.mark.gpu
 def test_gpu_depth_sort_three_forms_agree(gpu_lib):
     _sort_forms("cuda")
+
+
+# ---- the generic path's plane blur beyond 21 taps (k_blur_plane; round 5 compiled the LDS-free stream form there: 1 KB of scratch) ----
+def plane_blur_beyond_21_taps(dev, D, K):
+    """smoothen_voxels3d (dpc/util/point_cloud.py:139-145) as its own stage on a power-of-two grid -- the shape family the LDS-free
+    stream kernel serves up to 21 taps -- with 25 / 31 taps: forward and the adjoint (the gradient w.r.t. the input grid) against
+    the float64 NumPy oracle."""
+    B, sigma = 2, K / 6.0
+    rng = np.random.default_rng(K)
+    cfg = dpc_amd.default_config(vox_size=D, pc_gauss_kernel_size=K)
+    kern = dpc_amd.smoothing_kernel(cfg, sigma, device=dev)
+    taps = onp.smoothing_taps(D, -1, K, sigma)
+    vox_np = rng.uniform(0.0, 1.0, (B, D, D, D)).astype(np.float32)
+    vox = torch.tensor(vox_np[..., None], device=dev, requires_grad=True)
+    sm = dpc_amd.smoothen_voxels3d(cfg, vox, kern)
+    ref = onp.blur3d(vox_np.astype(np.float64), taps)
+    assert np.abs(sm.detach().cpu().numpy()[..., 0] - ref).max() <= 2e-6
+    w = rng.standard_normal((B, D, D, D))
+    g, = torch.autograd.grad(sm, [vox], torch.tensor(w[..., None], dtype=torch.float32, device=dev))
+    gref = onp.blur3d(w, [t[::-1] for t in taps], order=("z", "y", "x"))
+    assert np.abs(g.cpu().numpy()[..., 0] - gref).max() <= 1e-5 * np.abs(gref).max()
+
+
+@pytest.mark.parametrize("D,K", [(32, 25), (16, 31)])
+def test_emu_plane_blur_beyond_21_taps(emu, D, K):
+    plane_blur_beyond_21_taps("cpu", D, K)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,K", [(32, 25), (64, 31), (128, 27)])
+def test_gpu_plane_blur_beyond_21_taps(gpu_lib, D, K):
+    plane_blur_beyond_21_taps("cuda", D, K)
