@@ -173,6 +173,9 @@ def drain_watchdog(seconds=None):
     counter of earlier releases is gone) and exposes no call that waits for it: everything issued so far has completed
     (the caller synchronised), the next poll removes it, and 2.5 poll periods are waited for here.  0.25 s per
     recording; DPC_WATCHDOG_DRAIN_S=0 switches it off (scripts/rccl_capture_stress.py --drain 0 shows the abort)."""
+    # BEST EFFORT, by construction: a fixed pause sized for the watchdog's default 100 ms cadence.  It does not cover works of other
+    # process groups created between the pause and the capture, nor a watchdog slowed down by TORCH_NCCL_* settings (raise
+    # DPC_WATCHDOG_DRAIN_S accordingly); a collision that still happens ends in std::terminate inside ProcessGroupNCCL.
     if not active() or dist.get_backend() != "nccl":
         return
     if seconds is None:

@@ -185,8 +185,17 @@ class ModelPointCloud(object):
         follow_tap_counts: a recorded step runs the blur kernels of ONE tap count.  False (default): the full filter
         (cfg.pc_gauss_kernel_size taps) for the whole run, whatever sigma does -- one graph stays valid.  True: the
         filter is trimmed to the taps the current sigma still needs (util.point_cloud._flat_taps) and the CALLER
-        records the step again whenever effective_tap_counts() changes -- dpc_amd.graphs.RecordedStep(run,
-        key=projector.effective_tap_counts) does exactly that."""
+        records the step again whenever recording_key() changes -- the tap counts AND whether the GT filter is still on
+        (dpc_amd.graphs.RecordedStep(run, key=projector.recording_key) does exactly that).
+
+        cfg.pc_gauss_filter_gt with pc_gauss_filter_gt_switch_off (model_pc.py:398-404) is a HOST decision on sigma that a
+        recording freezes: a record-once caller (follow_tap_counts=False) would keep blurring -- or not blurring -- the GT
+        masks after sigma crosses 1.  That combination raises here; record again on recording_key() (follow_tap_counts=True)."""
+        cfg = self.cfg()
+        if not follow_tap_counts and getattr(cfg, "pc_gauss_filter_gt", False) and getattr(cfg, "pc_gauss_filter_gt_switch_off", False):
+            raise ValueError("pc_gauss_filter_gt_switch_off switches the GT blur off on the host when sigma falls below 1: a step "
+                             "recorded once would freeze that decision.  Use enable_graph_replay(follow_tap_counts=True) and record "
+                             "again whenever recording_key() changes (dpc_amd.graphs.RecordedStep(run, key=projector.recording_key))")
         if self._device is None or torch.device(self._device).type != "cuda":
             raise ValueError("graph replay needs the projector on a ROCm device")
         self._graph_replay = True

@@ -307,3 +307,14 @@ def test_emu_plane_blur_beyond_21_taps(emu, D, K):
 @pytest.mark.parametrize("D,K", [(32, 25), (64, 31), (128, 27)])
 def test_gpu_plane_blur_beyond_21_taps(gpu_lib, D, K):
     plane_blur_beyond_21_taps("cuda", D, K)
+
+
+def test_graph_replay_refuses_a_frozen_gt_switch():
+    """pc_gauss_filter_gt_switch_off is a host decision on sigma; a record-once caller would freeze it into the
+    graph.  enable_graph_replay(follow_tap_counts=False) raises for that configuration (before it looks at the device)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "chair_unsupervised"))
+    cfg = dpc_amd.default_config(vox_size=32, pc_gauss_kernel_size=5, pc_gauss_filter_gt=True, pc_gauss_filter_gt_switch_off=True)
+    m = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device="cpu")
+    with pytest.raises(ValueError, match="pc_gauss_filter_gt_switch_off"):
+        m.enable_graph_replay()
