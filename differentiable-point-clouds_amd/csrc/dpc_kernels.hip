@@ -116,7 +116,7 @@ int dpc_compiled_taps(int K) {
 
 int dpc_set_chunk_sparse(int mode) { return chunk_sparse_mode().exchange(mode < 0 ? -1 : (mode ? 1 : 0)); }
 
-int dpc_set_sparse_walk(int on) { return sparse_walk_mode().exchange(on ? 1 : 0); }
+int dpc_set_sparse_walk(int on) { return sparse_walk_mode().exchange(on == 2 ? 2 : (on ? 1 : 0)); }
 #ifdef DPC_EMU
 // (CPU test tier only) dead groups the emulated wavefronts of the z kernels took since the last call
 long long dpc_emu_dead_groups_take(void) { return dpc_emu_dead_groups().exchange(0); }

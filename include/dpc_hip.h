@@ -180,8 +180,10 @@ int dpc_set_chunk_sparse(int mode);
  * plane, dpc/util/drc.py:47-123, dpc/util/point_cloud.py:139-145): a wavefront of the fused collapse kernels skips, behind one
  * scalar branch per group of plane steps, the groups in which none of its rays has anything within the blur's reach, advancing
  * only the ray state -- in the dense walk's order with the dense walk's operations, so both walks agree bit for bit.
- * on != 0 (the default) enables it, 0 makes every wavefront walk every plane for the calls that follow; returns the previous
- * setting.  For A/B measurements and for the tests that compare the two walks. */
+ * on = 1 (the default) enables it where the library's per-shape rule launches the walking instantiations (chunk-sparse grids from
+ * 128-wide rows up, filters up to 11 taps), 2 wherever they are compiled (the tests of the walk on small grids), 0 makes every
+ * wavefront walk every plane for the calls that follow; returns the previous setting.  For A/B measurements and for the tests
+ * that compare the two walks. */
 int dpc_set_sparse_walk(int on);
 
 /* Bytes of scratch `dpc_project_forward` (direction 0) / `dpc_project_backward`

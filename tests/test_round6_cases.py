@@ -129,7 +129,7 @@ def both_walks_agree_bit_for_bit(lib, dev, B, N, D, K, sigma, Dz=-1, with_depth=
     res = []
     lib.dpc_set_chunk_sparse(cs)
     try:
-        for walk in (0, 1):
+        for walk in (0, 2):          # (2: the walking instantiations wherever they are compiled -- the rule alone starts at 128-wide rows)
             lib.dpc_set_sparse_walk(walk)
             t = lambda a: torch.tensor(a, device=dev, requires_grad=True)
             pc, pose, scale = t(inp["pc"]), t(inp["pose"]), t(inp["scale"])
@@ -157,8 +157,8 @@ WALK_CASES_EMU = [
     (2, 300, 32, 5, 0.9, -1, False, -1),
     (1, 300, 64, 9, 1.4, -1, True, -1),
     (1, 300, 64, 3, 0.6, -1, False, 1),        # 3 taps: k_zfwd walks groups of 12 planes, k_zbwd of 6
-    (1, 200, 64, 21, 3.0, -1, False, 0),       # dense layout, 21 taps, one loop body (64 planes: no run of empty planes is long enough)
-    (1, 200, 64, 23, 1.2, -1, False, 1),       # G2 saved through the widened mask (the !FROM_T walk)
+    (1, 200, 64, 21, 3.0, -1, False, 0),       # dense layout, 21 taps: no walking instantiation (both settings run the same kernels)
+    (1, 200, 64, 23, 1.2, -1, False, 1),       # G2 saved through the widened mask: ditto
     (1, 400, 128, 11, 1.6, 32, False, -1),     # the headline's row width, shallow to keep the emulation quick
     (1, 300, 96, 7, 1.0, 24, False, -1),       # padded rows: no chunk maps, plane occupancy only
 ]
@@ -170,14 +170,18 @@ def test_emu_both_walks_agree_bit_for_bit(emu, poison_mode, case):
     emu.dpc_emu_dead_groups_take()
     both_walks_agree_bit_for_bit(emu, "cpu", B, N, D, K, sigma, Dz=Dz, with_depth=depth, cs=cs)
     dead = emu.dpc_emu_dead_groups_take()
-    assert dead > 0 or K == 21, "no wavefront skipped a group: the case does not exercise the sparse walk"
+    assert dead > 0 or K > 11, "no wavefront skipped a group: the case does not exercise the sparse walk"   # (the walk is compiled up to 11 taps)
 
 
 def test_emu_sparse_walk_against_the_numpy_oracle(emu):
     """the sparse walk (default on) through the fused path against the float64 oracle, incl. depth upstream, translation, focal"""
     import parity_cases
     emu.dpc_emu_dead_groups_take()
-    parity_cases.fused_path_against_numpy_oracle("cpu", 2, 300, 64, 64, 5, 0.9, True, True)
+    emu.dpc_set_sparse_walk(2)
+    try:
+        parity_cases.fused_path_against_numpy_oracle("cpu", 2, 300, 64, 64, 5, 0.9, True, True)
+    finally:
+        emu.dpc_set_sparse_walk(1)
     assert emu.dpc_emu_dead_groups_take() > 0
 
 
