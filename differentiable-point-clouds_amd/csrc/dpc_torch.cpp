@@ -235,7 +235,7 @@ class ProjectFusedFn : public torch::autograd::Function<ProjectFusedFn> {
     }
     const Plan plan = plan_for(lib, api, (int)B, (int)N, (int)Dz, (int)D, (int)collapse, K[0], K[1], K[2]);
     const bool fused = (plan.layout & 2) != 0;
-    TORCH_CHECK_VALUE(R == 1 || fused, "views_per_cloud needs the fused path (vox_size a multiple of 4 that fills whole lanes of the next power of two in [32,256], odd kernel size 3..31)");
+    TORCH_CHECK_VALUE(R == 1 || fused, "views_per_cloud needs the fused path (vox_size a multiple of 4 in (16, 256], odd kernel size 3..31)");
     if (tgt.defined()) {
       TORCH_CHECK_VALUE(plan.drc, "the fused L2 epilogue lives in the DRC collapse kernel (ptn_max_projection is off it)");
       check_tensor(api, tgt, "l2 target", pc);
@@ -247,8 +247,7 @@ class ProjectFusedFn : public torch::autograd::Function<ProjectFusedFn> {
       TORCH_CHECK_VALUE(dstate.scalar_type() == at::kInt && dstate.numel() == 2 && dstate.is_contiguous() && dstate.device() == pc.device(),
                         "dropout state must be a contiguous int32 tensor {keep, seed} on the points' device");
     TORCH_CHECK_VALUE(fused || !((dropout_keep > 0 && dropout_keep < N) || dstate.defined()),
-                      "fused point dropout needs the fused path (vox_size a multiple of 4 that fills whole lanes of the next power of two in "
-                      "[32,256], odd kernel size 3..31, vox_size_z <= 256); use pc_point_dropout for this shape");
+                      "fused point dropout needs the fused path (vox_size a multiple of 4 in (16, 256], odd kernel size 3..31, vox_size_z <= 256); use pc_point_dropout for this shape");
     if (sgt.defined()) {
       TORCH_CHECK_VALUE(plan.sil_parts > 0, "the fused candidate-loss epilogue needs the fused path with the DRC collapse");
       TORCH_CHECK_VALUE(sil_C > 0 && B % sil_C == 0, "B=", B, " instances do not split into groups of ", sil_C, " pose candidates");

@@ -263,7 +263,7 @@ class ProjectFused(torch.autograd.Function):
         dev = pc.device
         plan = _fused_plan(lib, B, N, meta, K)
         if R > 1 and not plan.layout & 2:
-            raise ValueError("views_per_cloud needs the fused path (vox_size a multiple of 4 that fills whole lanes of the next power of two in [32,256], odd kernel size 3..31)")
+            raise ValueError("views_per_cloud needs the fused path (vox_size a multiple of 4 in (16, 256], odd kernel size 3..31)")
         tgt = meta.l2_target
         if tgt is not None:
             if not plan.drc:
@@ -277,8 +277,7 @@ class ProjectFused(torch.autograd.Function):
             if st.dtype != torch.int32 or st.numel() != 2 or not st.is_contiguous() or st.device != dev:
                 raise ValueError("dropout state must be a contiguous int32 tensor {keep, seed} on the points' device")
         if (0 < meta.dropout_keep < N or st is not None) and not plan.layout & 2:
-            raise ValueError("fused point dropout needs the fused path (vox_size a multiple of 4 that fills whole lanes of the next power "
-                             "of two in [32,256], odd kernel size 3..31, vox_size_z <= 256); use pc_point_dropout for this shape")
+            raise ValueError("fused point dropout needs the fused path (vox_size a multiple of 4 in (16, 256], odd kernel size 3..31, vox_size_z <= 256); use pc_point_dropout for this shape")
         sgt = meta.sil_gt
         sil = None
         if sgt is not None:

@@ -91,6 +91,9 @@ FUSED_CASES = [
     # round 4: grids narrower than the power-of-two lane geometry (rows padded inside the kernels)
     (2, 600, 48, 48, 5, 0.9, False, False),      # 48 on the 64-wide geometry: one strip per plane
     (2, 300, 24, 24, 5, 0.8, True, False),       # 24 on the 32-wide one
+    # round 6: widths that end inside a lane of that geometry (any multiple of 4: the padding is masked per 16-byte vector)
+    (1, 400, 68, 68, 5, 1.0, True, True),        # 68 on the 128-wide geometry (8 floats per lane): two strips
+    (2, 300, 36, 36, 7, 1.0, False, False),      # 36 on the 64-wide one
 ]
 
 
@@ -123,6 +126,12 @@ FUSED_CASES_GPU = FUSED_CASES + [
     (1, 2000, 128, 64, 27, 4.5, False, True),    # vox_size_z = 64 at 128: Kz = 13
     (1, 1500, 32, 32, 25, 4.2, False, False),    # 25 taps on 32-wide rows: the halo comes from 12 columns away
     (1, 2500, 96, 96, 29, 4.8, False, False),    # padded rows
+    # round 6: widths that end inside a lane (the reference accepts any vox_size, default_config.yaml:77)
+    (4, 8000, 100, 100, 11, 1.6, True, False),   # bench.py --vox 100
+    (2, 8000, 200, 200, 11, 2.0, False, True),   # 200 on the 256-wide geometry (16 floats per lane), seven strips
+    (2, 6000, 52, 52, 21, 3.0, False, False),    # 52 on 64 with 21 taps: dense gather flow
+    (1, 3000, 132, 132, 5, 1.0, False, False),   # 132 on 256: half the geometry empty
+    (1, 2000, 100, 40, 9, 1.4, False, False),    # vox_size_z != vox_size on such a width
 ]
 DENSE_GATHER_CASE_EMU = (1, 3000, 32, 32, 5, 0.8, False, False)    # ~150+ points per occupied plane at D = 32
 

@@ -321,14 +321,16 @@ def test_emu_padded_grids_take_the_fused_path(emu, case):
 
 
 def test_fused_width_rule():
-    """which vox_size values the fused path takes: D fills whole lanes of the next power-of-two geometry"""
+    """which vox_size values the fused path takes: every multiple of 4 in (16, 256] -- the rows are padded inside the kernels to the
+    next power-of-two geometry (round 4: only widths that fill whole lanes of it; round 6: the padding is masked per 16-byte vector
+    everywhere, so any multiple of 4 -- 100, 136, ... no longer fall to the generic path, 3 x slower)"""
     import ctypes
     import dpc_amd
     lib = dpc_amd.get_library()
     P = dpc_amd._capi.DpcParams(2.0, 1.875, 1e-5, 10.0, 1, 0, 0, 0, 0)
     fused = lambda D: bool(lib.dpc_saved_layout(ctypes.byref(dpc_amd._capi.DpcShape(2, 100, 32, D, 5, 5, 5)), ctypes.byref(P)) & 2)
-    assert all(fused(D) for D in (20, 24, 28, 32, 40, 48, 56, 64, 72, 80, 96, 112, 128, 144, 160, 192, 240, 256))
-    assert not any(fused(D) for D in (16, 18, 30, 33, 50, 66, 100, 130, 136, 257, 260))
+    assert all(fused(D) for D in (20, 24, 28, 32, 40, 48, 56, 64, 72, 80, 96, 112, 128, 144, 160, 192, 240, 256, 36, 44, 52, 68, 100, 132, 136, 200, 252))
+    assert not any(fused(D) for D in (16, 12, 18, 30, 33, 50, 66, 98, 130, 254, 257, 260))
 
 
 def test_emu_view_walking_order_does_not_change_results(tmp_path):
