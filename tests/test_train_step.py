@@ -24,7 +24,8 @@ def _grads(ts, nets, cfg, images, masks, world=1, ddp=False, buckets=False):
     torch.manual_seed(0)
     net = nets.Im2PointCloud(cfg, image_size=32, f_dim=4, fc_dim=32, z_dim=32)
     model = torch.nn.parallel.DistributedDataParallel(net) if ddp else net
-    red = dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=0.05) if buckets else None   # several buckets
+    red = (dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=0.05, gather=buckets if isinstance(buckets, str) else "accumulate")
+           if buckets else None)   # several buckets
     proj = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device="cpu")
     outputs = proj.replicate_outputs(model(images))
     outputs = proj.compute_projection({"masks": masks}, outputs, is_training=False)
@@ -60,9 +61,12 @@ def _worker(rank, world, port, ret):
     g, loss = _grads(ts, nets, _toy_cfg(ts, hi - lo), images[2 * lo:2 * hi], masks[2 * lo:2 * hi], world, ddp=True)
     # the recordable reducer (what bench.py --config 3 --graph --gpus N and train_step.py --graph use instead of DDP)
     gb, _ = _grads(ts, nets, _toy_cfg(ts, hi - lo), images[2 * lo:2 * hi], masks[2 * lo:2 * hi], world, buckets=True)
+    # ... and its copy mode (round 6: autograd moves the gradients in, one multi-tensor copy packs each bucket)
+    gc, _ = _grads(ts, nets, _toy_cfg(ts, hi - lo), images[2 * lo:2 * hi], masks[2 * lo:2 * hi], world, buckets="copy")
     if rank == 0:
         ret["grads"] = {k: v.numpy() for k, v in g.items()}
         ret["grads_buckets"] = {k: v.numpy() for k, v in gb.items()}
+        ret["grads_buckets_copy"] = {k: v.numpy() for k, v in gc.items()}
     dpc_amd.distributed.finalize()
 
 
@@ -84,8 +88,9 @@ def test_training_step_runs_and_ddp_matches_single_process(emu):
     for k, v in ref.items():
         a, b = ret["grads"][k], v.numpy()
         assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max()), k
-        a = ret["grads_buckets"][k]                  # GradBuckets: same averages as DDP
-        assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max()), k
+        for mode in ("grads_buckets", "grads_buckets_copy"):          # GradBuckets, both gather modes: same averages as DDP
+            a = ret[mode][k]
+            assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(b).max()), (mode, k)
 
 
 def test_grad_buckets_step_equals_plain_step(emu):
@@ -100,17 +105,18 @@ def test_grad_buckets_step_equals_plain_step(emu):
     cfg = _toy_cfg(ts, 2)
     images, masks = _data(2)
     finals = []
-    for use_buckets in (False, True):
+    for use_buckets in (False, "accumulate", "copy"):
         torch.manual_seed(0)
         net = nets.Im2PointCloud(cfg, image_size=32, f_dim=4, fc_dim=32, z_dim=32)
         proj = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device="cpu")
         opt = torch.optim.Adam(net.parameters(), lr=1e-3)
-        red = dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=0.05) if use_buckets else None
+        red = dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=0.05, gather=use_buckets) if use_buckets else None
         for _ in range(2):
             ts.train_step(net, proj, {"images": images, "masks": masks}, opt, is_training=False, buckets=red)
         finals.append({n: p.detach().clone() for n, p in net.named_parameters()})
     for k in finals[0]:
         assert torch.allclose(finals[0][k], finals[1][k], rtol=0, atol=1e-6), k
+        assert torch.allclose(finals[0][k], finals[2][k], rtol=0, atol=1e-6), k
 
 
 def test_optimizer_step_changes_parameters(emu):
