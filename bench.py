@@ -116,7 +116,8 @@ def build_train_case(args, device, rank, world):
         # backward-overlapped all-reduce is issued by gradient hooks instead (dpc_amd.distributed.GradBuckets)
         # (gather="copy": autograd moves the gradients in and one multi-tensor copy packs each bucket -- no add kernel per parameter,
         # no zero-fill; DPC_BUCKET_GATHER=accumulate is the round-5 form, for A/B)
-        buckets = dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=64, gather=os.environ.get("DPC_BUCKET_GATHER", "copy"))
+        buckets = dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=float(os.environ.get("DPC_BUCKET_MB", "64")),
+                                                   gather=os.environ.get("DPC_BUCKET_GATHER", "copy"))
     elif dist_on:
         ddp_kw = dict(device_ids=[device.index]) if device.type == "cuda" else {}
         model = torch.nn.parallel.DistributedDataParallel(net, bucket_cap_mb=64, gradient_as_bucket_view=True, **ddp_kw)

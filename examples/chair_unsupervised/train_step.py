@@ -104,7 +104,7 @@ def main():
     model, buckets = net, None
     dist_on = dd.active()          # several ranks, or a forced one-rank group (DPC_FORCE_DIST=1: the one-GPU rehearsal)
     if dist_on and args.graph:
-        buckets = dd.GradBuckets(net.parameters(), bucket_mb=64)       # recordable bucketed all-reduce (no DDP wrapper)
+        buckets = dd.GradBuckets(net.parameters(), bucket_mb=64, gather="copy")       # recordable bucketed all-reduce (no DDP wrapper)
     elif dist_on:
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[device.index], bucket_cap_mb=64,
                                                           gradient_as_bucket_view=True)
