@@ -197,3 +197,48 @@ def yblur_blocks(cfg_id, B=None):
 if __name__ == "__main__" and os.environ.get("YBLUR"):
     yblur_blocks(2)
     yblur_blocks(5, B=4)
+
+
+def balance_static_radial(cfg_id, B=None):
+    """static deal by distance from the image centre (snake over the SIMD groups of a view) against the Latin squares and a deal by measured cost"""
+    c, mark = marks_for(cfg_id, B=B)
+    D, K = c["D"], c["K"]; Dz = D; h = K // 2; G = K
+    NB = mark.shape[0]
+    NC, RG = D // 32, D // 4
+    tile_any = mark.reshape(NB, Dz, RG, 4, NC).any(3)
+    for name, T, look in (("zfwd", Dz + h, K), ("zbwd", Dz + 2 * h, 2 * K - 1)):
+        ng = (T + G - 1) // G
+        cost = np.zeros((NB, RG, NC))
+        for g in range(ng):
+            lo, hi = max(g * G - look, 0), min(g * G + G - 1, Dz - 1)
+            dead = ~tile_any[:, lo:hi + 1].any(1) if hi >= lo else np.ones((NB, RG, NC), bool)
+            cost += np.where(dead, 0.13, 1.0)
+        cost /= ng
+        flat = cost.reshape(NB, -1)                      # tile t = rg * NC + c
+        NT = RG * NC
+        rg, cc = np.divmod(np.arange(NT), NC)
+        rad = ((rg + 0.5) * 4 - D / 2) ** 2 + ((cc + 0.5) * 32 - D / 2) ** 2
+        def snake(order_per_view):
+            gs = NT // 4
+            sums = np.zeros((NB, gs))
+            for b in range(NB):
+                o = order_per_view[b]
+                for r, t in enumerate(o):
+                    q, pos = divmod(r, gs)
+                    k = gs - 1 - pos if q & 1 else pos
+                    sums[b, k] += flat[b, t]
+            return sums / 4
+        s_rad = snake([np.argsort(rad, kind="stable")] * NB)
+        s_dyn = snake([np.argsort(-flat[b], kind="stable") for b in range(NB)])
+        # global dynamic deal (all views together)
+        allc = flat.reshape(-1); M = allc.size; gs = M // 4
+        o = np.argsort(-allc, kind="stable"); sums = np.zeros(gs)
+        for r, t in enumerate(o):
+            q, pos = divmod(r, gs); k = gs - 1 - pos if q & 1 else pos; sums[k] += allc[t]
+        print("cfg%d %s: mean %.3f | radial static: busiest SIMD %.3f | by measured cost per view %.3f | over all views %.3f" % (
+            cfg_id, name, flat.mean(), s_rad.max(), s_dyn.max(), sums.max() / 4))
+
+
+if __name__ == "__main__" and os.environ.get("RADIAL"):
+    balance_static_radial(2)
+    balance_static_radial(5, B=8)
