@@ -120,6 +120,8 @@ int dpc_set_sparse_walk(int on) { return sparse_walk_mode().exchange(on == 2 ? 2
 #ifdef DPC_EMU
 // (CPU test tier only) dead groups the emulated wavefronts of the z kernels took since the last call
 long long dpc_emu_dead_groups_take(void) { return dpc_emu_dead_groups().exchange(0); }
+// ... wavefronts of the 1024-thread z kernels that were dealt another tile of their work-group (zdeal_tiles) since the last call
+long long dpc_emu_deals_take(void) { return dpc_emu_deals().exchange(0); }
 #endif
 
 int dpc_profile_enable(int on) {

@@ -26,7 +26,7 @@ for spec in sys.argv[1:]:
     name = os.path.basename(path) + "".join("@" + f for f in flags)
     libs.append((name, dpc_amd._capi.DpcLibrary(os.path.abspath(path))))
     opts[name] = flags
-rounds, steps = 3, 20
+rounds, steps = int(os.environ.get("AB_ROUNDS", "3")), int(os.environ.get("AB_STEPS", "20"))
 res = {n: {"ms": [], "k": {}} for n, _ in libs}
 for r in range(rounds):
     for name, lib in libs:

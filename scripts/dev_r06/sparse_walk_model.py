@@ -242,3 +242,47 @@ def balance_static_radial(cfg_id, B=None):
 if __name__ == "__main__" and os.environ.get("RADIAL"):
     balance_static_radial(2)
     balance_static_radial(5, B=8)
+
+
+def balance_within_wg(cfg_id, B=None):
+    """the 16 tiles of a 1024-thread work-group (Latin squares) re-dealt INSIDE the work-group by measured cost (sort 16, snake over the
+    4 SIMDs) -- no extra kernel, no global ranks: how close does that get to the global deal?"""
+    c, mark = marks_for(cfg_id, B=B)
+    D, K = c["D"], c["K"]; Dz = D; h = K // 2; G = K
+    NB = mark.shape[0]
+    NC, RG = D // 32, D // 4
+    tile_any = mark.reshape(NB, Dz, RG, 4, NC).any(3)
+    for name, T, look in (("zfwd", Dz + h, K), ("zbwd", Dz + 2 * h, 2 * K - 1)):
+        ng = (T + G - 1) // G
+        cost = np.zeros((NB, RG, NC))
+        for g in range(ng):
+            lo, hi = max(g * G - look, 0), min(g * G + G - 1, Dz - 1)
+            dead = ~tile_any[:, lo:hi + 1].any(1) if hi >= lo else np.ones((NB, RG, NC), bool)
+            cost += np.where(dead, 0.13, 1.0)
+        cost /= ng
+        mul2 = [0, 2, 3, 1]
+        q = max(NC // 4, 1)
+        nwg = (RG // 4) * q if NC >= 4 else RG // 8
+        latin = np.zeros((NB, nwg, 4)); local = np.zeros((NB, nwg, 4))
+        for g in range(nwg):
+            tiles = []
+            for w in range(16):
+                s, j = w & 3, w >> 2
+                a, b = s ^ j, mul2[s] ^ j
+                if NC >= 4:
+                    rg, cc = g // q + a * (RG // 4), g % q + q * b
+                else:
+                    rg, cc = g + a * (RG // 4) + (b >> 1) * (RG // 8), b & 1
+                latin[:, g, s] += cost[:, rg, cc]
+                tiles.append(cost[:, rg, cc])
+            t = -np.sort(-np.stack(tiles, -1), axis=-1)          # [NB, 16] descending
+            for r in range(16):
+                qq, pos = divmod(r, 4)
+                local[:, g, 3 - pos if qq & 1 else pos] += t[:, r]
+        print("cfg%d %s: mean %.3f | Latin squares: busiest SIMD %.3f | re-dealt inside each work-group: %.3f | busiest work-group / 4: %.3f" % (
+            cfg_id, name, cost.mean(), latin.max() / 4, local.max() / 4, latin.sum(-1).max() / 16))
+
+
+if __name__ == "__main__" and os.environ.get("WITHIN"):
+    balance_within_wg(2)
+    balance_within_wg(5, B=8)

@@ -69,6 +69,9 @@ def emu_library():
     lib.dpc_emu_dead_groups_take = lib._dll.dpc_emu_dead_groups_take
     lib.dpc_emu_dead_groups_take.restype = ctypes.c_longlong
     lib.dpc_emu_dead_groups_take.argtypes = []
+    lib.dpc_emu_deals_take = lib._dll.dpc_emu_deals_take         # ... wavefronts dealt another tile of their work-group (zdeal_tiles)
+    lib.dpc_emu_deals_take.restype = ctypes.c_longlong
+    lib.dpc_emu_deals_take.argtypes = []
     return lib
 
 

@@ -215,6 +215,8 @@ static inline void dpc_pk_mul_tap(dpc_v2f& acc, dpc_v2f pair, dpc_v2f v) {
 
 static inline void dpc_consume(float) {}
 static inline float __fdividef(float a, float b) { return a / b; }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only used on wave-uniform values
 static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }          // (a spin on a counter another work-group's OS thread advances)
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {

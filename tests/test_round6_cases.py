@@ -168,9 +168,12 @@ WALK_CASES_EMU = [
 def test_emu_both_walks_agree_bit_for_bit(emu, poison_mode, case):
     B, N, D, K, sigma, Dz, depth, cs = case
     emu.dpc_emu_dead_groups_take()
+    emu.dpc_emu_deals_take()
     both_walks_agree_bit_for_bit(emu, "cpu", B, N, D, K, sigma, Dz=Dz, with_depth=depth, cs=cs)
     dead = emu.dpc_emu_dead_groups_take()
     assert dead > 0 or K > 11, "no wavefront skipped a group: the case does not exercise the sparse walk"   # (the walk is compiled up to 11 taps)
+    # 128-wide chunk-sparse rows run the 1024-thread form: its wavefronts re-deal the work-group's tiles by cost (zdeal_tiles)
+    assert (emu.dpc_emu_deals_take() > 0) == (D == 128), "the tile deal ran where it should not, or not where it should"
 
 
 def test_emu_sparse_walk_against_the_numpy_oracle(emu):
@@ -322,3 +325,62 @@ def test_graph_replay_refuses_a_frozen_gt_switch():
     m = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device="cpu")
     with pytest.raises(ValueError, match="pc_gauss_filter_gt_switch_off"):
         m.enable_graph_replay()
+
+
+# ---- the tiles of a 1024-thread work-group re-dealt to its wavefronts by cost (zdeal_tiles) ------------------------------------------
+_DEAL_SCRIPT = r'''
+import hashlib, json, os, sys
+root, dev = sys.argv[1], sys.argv[2]
+sys.path[:0] = [root, os.path.join(root, "tests")]
+import numpy as np, torch
+import dpc_amd
+from helpers import synth
+if dev == "cpu":
+    dpc_amd._capi.set_library(dpc_amd._capi.DpcLibrary(os.path.join(root, "tests", "hipemu", "libdpc_emu.so"), host_memory=True))
+B, N, D, K, sigma, Dz = (1, 400, 128, 11, 1.6, 32) if dev == "cpu" else (4, 8000, 256, 11, 2.0, -1)
+inp = synth.make_inputs(B, N, 33)
+inp["pc"][:, :, 1] *= np.float32(0.5)                    # (a lopsided cloud: the tiles of a work-group cost differently)
+cfg = dpc_amd.default_config(vox_size=D, vox_size_z=Dz, pc_gauss_kernel_size=K)
+kern = dpc_amd.smoothing_kernel(cfg, sigma, device=dev)
+t = lambda a: torch.tensor(a, device=dev, requires_grad=True)
+pc, pose, scale = t(inp["pc"]), t(inp["pose"]), t(inp["scale"])
+out = dpc_amd.pointcloud_project_fast(cfg, pc, pose, None, None, kern, scaling_factor=scale)
+w = torch.tensor(np.random.default_rng(6).standard_normal(tuple(out["proj"].shape)).astype(np.float32), device=dev)
+g = torch.autograd.grad(out["proj"], [pc, pose, scale], w)
+h = lambda x: hashlib.sha256(np.ascontiguousarray(x.detach().cpu().numpy()).tobytes()).hexdigest()
+print(json.dumps({"proj": h(out["proj"]), "depth": h(out["proj_depth"]), "dpc": h(g[0]), "nonzero": bool(g[0].abs().max() > 0),
+                  "dpose": g[1].cpu().numpy().astype(np.float64).ravel().tolist(), "dscale": g[2].cpu().numpy().astype(np.float64).ravel().tolist()}))
+'''
+
+
+def _deal_forms(dev):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for form in ("0", "1", "2"):
+        env = dict(os.environ, DPC_ZDEAL=form, DPC_TEST_HOOKS="1")
+        out = subprocess.run([sys.executable, "-c", _DEAL_SCRIPT, root, dev], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[form] = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["0"]["nonzero"]
+    for form in ("1", "2"):
+        for k in ("proj", "depth", "dpc"):          # which wavefront walks a tile changes nothing a ray computes
+            assert res[form][k] == res["0"][k], (form, k)
+        for k in ("dpose", "dscale"):               # per-view sums: the order of the work-group's partials / float atomics
+            a, b = np.array(res["0"][k]), np.array(res[form][k])
+            assert np.abs(a - b).max() <= 2e-5 * max(np.abs(a).max(), 1e-30), (form, k)
+
+
+def test_emu_tile_deal_changes_no_ray():
+    """DPC_ZDEAL=0 / 1 / 2 (read once: a process each): the Latin-square tiles as they come / k_zbwd's wavefronts re-deal their
+    work-group's 16 tiles by cost (k_zfwd from 256-wide rows) / both kernels wherever they run the 1024-thread form.  Images, depth
+    and point gradients bit for bit; the per-view pose / scale sums to their summation-order noise."""
+    _deal_forms("cpu")
+
+
+@pytest.mark.gpu
+def test_gpu_tile_deal_changes_no_ray(gpu_lib):
+    _deal_forms("cuda")
