@@ -21,3 +21,11 @@ done
 DPC_ZBIG=0 timeout 300 python bench.py --no-cpu-baseline > "$OUT/bench_zbig0.json" 2> "$OUT/bench_zbig0.err"
 python -c "
 import json; j=json.load(open('$OUT/bench_zbig0.json')); print('DPC_ZBIG=0 value %.0f ms_per_step %.4f median %.4f' % (j['value'], j['ms_per_step'], j['timing']['ms_per_step_median']), j['roofline']['kernel_ms_per_step'])" | tee -a "$OUT/boxes.txt"
+DPC_ZDEAL=0 timeout 300 python bench.py --no-cpu-baseline > "$OUT/bench_zdeal0.json" 2> "$OUT/bench_zdeal0.err"
+python -c "
+import json; j=json.load(open('$OUT/bench_zdeal0.json')); print('DPC_ZDEAL=0 value %.0f ms_per_step %.4f median %.4f' % (j['value'], j['ms_per_step'], j['timing']['ms_per_step_median']), j['roofline']['kernel_ms_per_step'])" | tee -a "$OUT/boxes.txt"
+for C in 5 5; do
+  timeout 300 python bench.py --config $C --steps 30 --warmup 5 --no-cpu-baseline > "$OUT/bench_cfg$C.json" 2> "$OUT/bench_cfg$C.err"
+  python -c "
+import json; j=json.load(open('$OUT/bench_cfg$C.json')); print('cfg$C value %.0f ms_per_step %.4f median %.4f bound %s' % (j['value'], j['ms_per_step'], j['timing']['ms_per_step_median'], j['roofline']['bound']), j['roofline']['kernel_ms_per_step'])" | tee -a "$OUT/boxes.txt"
+done
