@@ -246,7 +246,7 @@ class GradBuckets(object):
       the buckets before it), so ranks whose autograd graphs finish buckets in different orders -- or leave
       different parameters without a gradient -- still issue matching all-reduces."""
 
-    def __init__(self, params, bucket_mb=64, process_group=None, gather="accumulate"):
+    def __init__(self, params, bucket_mb=64, process_group=None, gather="accumulate", average="auto"):
         """gather="accumulate" (default): every p.grad IS its bucket view for the whole run; autograd accumulates into it in
         place (one add kernel per parameter and step -- ~100 launches of a few microseconds for the 33 M-parameter nets -- plus the
         zero-fill of the buckets by zero_()).  gather="copy" (round 6): the .grad tensors are left to autograd (None before the
@@ -257,12 +257,25 @@ class GradBuckets(object):
         there, against 2.54 ms without a reducer."""
         if gather not in ("accumulate", "copy"):
             raise ValueError("gather must be 'accumulate' or 'copy'")
+        if average not in ("auto", "collective", "divide"):
+            raise ValueError("average must be 'auto', 'collective' or 'divide'")
         self.gather = gather
         self.group = process_group
         self.reduce = active()              # a process group exists (possibly of ONE rank): the collectives are issued
         self.world = dist.get_world_size(process_group) if self.reduce else 1
-        self.in_collective_average = (self.reduce and dist.get_backend(process_group) == "nccl"
-                                      and os.environ.get("DPC_BUCKET_AVG", "1") == "1")
+        # Where the division by the world size happens.  "auto": inside the collective under RCCL (ReduceOp.AVG) when there is
+        # more than one rank; with ONE rank the average IS the sum, so the all-reduce goes out as a plain SUM -- every call,
+        # stream and graph edge is still there, but RCCL has nothing to do (its one-rank AVG is a pre-multiplied-sum kernel over
+        # the bucket plus host-side setup: measured, the recorded training step under a one-rank group 2.93 -> 2.61 ms against
+        # 2.53 without a reducer, profiles/r06/rccl_world1.txt); other backends sum and divide afterwards.  "collective": AVG
+        # whenever the backend has it, also with one rank (what rounds 5 and 6 quoted as the world-1 overhead); "divide": always
+        # sum, then divide.  DPC_BUCKET_AVG=1 / 0 in the environment forces "collective" / "divide" (bench.py's A/B switch).
+        env = os.environ.get("DPC_BUCKET_AVG")
+        if env in ("0", "1"):
+            average = "collective" if env == "1" else "divide"
+        self.average = average
+        self.in_collective_average = self.reduce and dist.get_backend(process_group) == "nccl" and average != "divide"
+        self._avg_op = self.in_collective_average and (self.world > 1 or average == "collective")
         params = [p for p in params if p.requires_grad]
         limit = int(bucket_mb * (1 << 20))
         # buckets in REVERSE parameter order: the backward pass produces the last layers' gradients first
@@ -320,7 +333,7 @@ class GradBuckets(object):
                     sys.stderr.write("[GradBuckets] bucket %d issued from thread %s, stream %s, capturing %s\n" % (
                         self._next, threading.current_thread().name, torch.cuda.current_stream(),
                         torch.cuda.is_current_stream_capturing()))
-                op = dist.ReduceOp.AVG if self.in_collective_average else dist.ReduceOp.SUM
+                op = dist.ReduceOp.AVG if self._avg_op else dist.ReduceOp.SUM
                 self._works.append(dist.all_reduce(self.buckets[self._next][0], op=op, group=self.group, async_op=True))
             self._next += 1
 

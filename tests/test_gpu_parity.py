@@ -805,12 +805,13 @@ assert torch.equal(out, torch.arange(1024, device=dev, dtype=torch.float32))
 cfg = ts.make_cfg(batch_size=2, pc_point_dropout=1.0)
 inputs = ts.synthetic_batch(cfg, dev, 128, seed=0)
 grads = {}
-for mode in ("plain", "ddp", "buckets"):
+for mode in ("plain", "ddp", "buckets", "buckets_avg"):       # (buckets: with one rank the all-reduce goes out as a SUM; buckets_avg: RCCL's AVG)
     torch.manual_seed(0)
     net = Im2PointCloud(cfg, 128).to(dev)
     model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index]) if mode == "ddp" else net
-    red = dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=16) if mode == "buckets" else None
-    assert red is None or (red.reduce and red.in_collective_average and len(red.buckets) > 1)
+    red = (dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=16, average="collective" if mode == "buckets_avg" else "auto")
+           if mode.startswith("buckets") else None)
+    assert red is None or (red.reduce and red.in_collective_average and len(red.buckets) > 1 and red._avg_op == (mode == "buckets_avg"))
     proj = dpc_amd.model_pc.ModelPointCloud(cfg, global_step=0, device=dev)
     def run():
         o = proj.compute_projection(inputs, proj.replicate_outputs(model(inputs["images"])), is_training=False)
@@ -819,14 +820,14 @@ for mode in ("plain", "ddp", "buckets"):
             red.finish()
     run()
     grads[mode] = [p.grad.clone() for p in net.parameters()]
-    if mode == "buckets":          # the same step recorded (collectives inside the graph) and replayed twice
+    if mode.startswith("buckets"):   # the same step recorded (collectives inside the graph) and replayed twice
         red.zero_()
         step = dpc_amd.graphs.RecordedStep(lambda: (red.zero_(), run())[1], world=1, device=dev, collectives=True)
         step(); step()
         torch.cuda.synchronize()
-        grads["replayed"] = [p.grad.clone() for p in net.parameters()]
+        grads["replayed_" + mode] = [p.grad.clone() for p in net.parameters()]
 ref = grads["plain"]
-for mode in ("ddp", "buckets", "replayed"):
+for mode in ("ddp", "buckets", "buckets_avg", "replayed_buckets", "replayed_buckets_avg"):
     worst = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-12)) for a, b in zip(grads[mode], ref))
     print("WORST", mode, worst)
     assert worst < 1e-5, (mode, worst)
