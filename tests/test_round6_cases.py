@@ -384,3 +384,24 @@ def test_emu_tile_deal_changes_no_ray():
 @pytest.mark.gpu
 def test_gpu_tile_deal_changes_no_ray(gpu_lib):
     _deal_forms("cuda")
+
+
+# ---- GradBuckets: where the division by the world size happens (average=...) ---------------------------------------------------
+def test_grad_buckets_average_policy(monkeypatch):
+    """average="auto" | "collective" | "divide" and the DPC_BUCKET_AVG override: without a process group nothing is averaged in a
+    collective whatever is asked; a bad value is refused.  (Under RCCL: tests/test_gpu_parity.py, the one-rank group -- "auto" sends a
+    one-rank average out as a SUM, "collective" as RCCL's AVG; gloo sums and divides: tests/test_distributed.py.)"""
+    net = torch.nn.Linear(4, 3)
+    with pytest.raises(ValueError, match="average"):
+        dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=1, average="mean")
+    for avg in ("auto", "collective", "divide"):
+        net = torch.nn.Linear(4, 3)
+        red = dpc_amd.distributed.GradBuckets(net.parameters(), bucket_mb=1, gather="copy", average=avg)
+        assert red.average == avg and red.in_collective_average is False and red._avg_op is False
+        net(torch.ones(2, 4)).sum().backward()
+        red.finish()
+        assert torch.equal(net.weight.grad, torch.full((3, 4), 2.0))
+    monkeypatch.setenv("DPC_BUCKET_AVG", "0")
+    assert dpc_amd.distributed.GradBuckets(torch.nn.Linear(2, 2).parameters(), average="collective").average == "divide"
+    monkeypatch.setenv("DPC_BUCKET_AVG", "1")
+    assert dpc_amd.distributed.GradBuckets(torch.nn.Linear(2, 2).parameters()).average == "collective"
